@@ -1,0 +1,163 @@
+/*
+ * taco.h - C ABI of libtaco_hip.so, the MI355X (gfx950) implementation of the
+ * cadia-lvl/tacotron synthesis path.
+ *
+ * The reference has no FFI: its de-facto boundary is the single
+ *     wav = session.run(self.wav_output, feed_dict={inputs, input_lengths})
+ * at /root/reference/synthesizer.py:39-43 plus the model attributes
+ * mel_outputs / linear_outputs / alignments (model/tacotron.py:53-56).  Each entry point
+ * below replaces one slice of that graph and cites the reference code it stands for.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch / HIP types in signatures
+ *    (taco_stream_t is a hipStream_t passed as void*; NULL = the default stream).
+ *  - All tensor pointers are DEVICE pointers owned by the caller, contiguous row-major,
+ *    fp32 / int32, 16-byte aligned.  Weights handed to taco_create are HOST pointers.
+ *  - Every call returns 0 on success, <0 on error; taco_last_error() gives the message
+ *    (thread-local).  No exception crosses the boundary.
+ *  - A handle is bound to one device and is not thread-safe: one handle per GPU/stream.
+ *  - After taco_create the library allocates nothing: all scratch comes from the
+ *    caller's workspace of at least taco_workspace_bytes() bytes.  Calls are
+ *    asynchronous on `stream`; the workspace must stay alive until they finish.
+ */
+#ifndef TACO_H_
+#define TACO_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct taco_ctx* taco_handle;
+typedef void* taco_stream_t;
+
+/* Shapes of the graph; field-for-field the model/audio/eval values of
+ * /root/reference/hparams.py:13-21,25-51,65-67 (hop/win already derived as
+ * tools/audio.py:162-163 does). */
+typedef struct TacoHParams {
+    int32_t num_chars;            /* len(text.characters.chars) = 95, data/batch.py:38 */
+    int32_t embedded_depth;       /* 256 */
+    int32_t prenet_depth1;        /* 256 */
+    int32_t prenet_depth2;        /* 128 */
+    int32_t encoder_K;            /* 16 */
+    int32_t encoder_bank_filters; /* 128 */
+    int32_t encoder_proj1;        /* 128 */
+    int32_t encoder_proj2;        /* 128 */
+    int32_t encoder_proj_width;   /* 3 */
+    int32_t encoder_highways;     /* 4 */
+    int32_t encoder_highway_depth;/* 128 */
+    int32_t encoder_gru_cells;    /* 128 */
+    int32_t attention_depth;      /* 256 */
+    int32_t decoder_depth;        /* 256 */
+    int32_t num_mels;             /* 80 */
+    int32_t outputs_per_step;     /* 5 */
+    int32_t decoder_K;            /* 8 (post-CBHG) */
+    int32_t decoder_bank_filters; /* 128 */
+    int32_t decoder_proj1;        /* 256 */
+    int32_t decoder_proj2;        /* 80 */
+    int32_t decoder_proj_width;   /* 3 */
+    int32_t decoder_highways;     /* 4 */
+    int32_t decoder_highway_depth;/* 128 */
+    int32_t decoder_gru_cells;    /* 128 */
+    int32_t num_freq;             /* 1025 */
+    int32_t n_fft;                /* 2048 */
+    int32_t hop_length;           /* 300 */
+    int32_t win_length;           /* 1200 */
+    float   min_level_db;         /* -100 */
+    float   ref_level_db;         /* 20 */
+    float   power;                /* 1.5 */
+    int32_t max_iters;            /* 200 */
+    int32_t griffin_lim_iters;    /* 60 */
+} TacoHParams;
+
+/* One TF variable of the inference graph: name relative to `model/inference/`
+ * (the scopes opened at synthesizer.py:23 and model/tacotron.py:31), host data, shape. */
+typedef struct TacoWeightEntry {
+    const char*  name;
+    const float* data;
+    int32_t      ndim;
+    int64_t      dims[4];
+} TacoWeightEntry;
+
+const char* taco_last_error(void);
+
+/* Replaces graph construction + `saver.restore` (synthesizer.py:19-34): copies, folds
+ * (batch-norm -> scale/shift) and re-packs the weights on `device`. */
+int taco_create(const TacoHParams* hp, const TacoWeightEntry* weights, int32_t n_weights,
+                int32_t device, taco_handle* out);
+void taco_destroy(taco_handle h);
+
+/* Upper bound of the scratch any entry point needs for these sizes. */
+size_t taco_workspace_bytes(taco_handle h, int32_t B, int32_t T_in, int32_t max_iters);
+
+/* Encoder: embedding lookup (data/batch.py:36-40) -> prenet (model/encoder.py:26-37,
+ * model/modules.py:4-28, dropout = identity at inference) -> CBHG K=16
+ * (model/encoder.py:39-63, model/modules.py:30-98; BiGRU masked by `lens`).
+ * ids [B,T_in] int32 right-padded with 0, lens [B] int32 -> enc_out [B,T_in,2*gru]. */
+int taco_encode(taco_handle h, const int32_t* ids, const int32_t* lens, int32_t B, int32_t T_in,
+                float* enc_out, void* ws, size_t ws_bytes, taco_stream_t stream);
+
+/* Autoregressive decoder loop: model/decoder.py:18-42 (AttentionWrapper(DecoderPrenetWrapper(
+ * GRUCell), BahdanauAttention), ConcatOutputAndAttentionWrapper, MultiRNNCell, r-frame
+ * OutputProjectionWrapper, dynamic_decode), model/rnn_wrappers.py:24-26,51-53,
+ * model/helpers.py:47-85 (TestingHelper: <GO> frame, feed last of r frames, all-zero stop)
+ * and the alignment transpose of model/tacotron.py:51.
+ *   mel   [B, max_iters*r, num_mels]   (rows past steps_run*r are zero)
+ *   align [B, T_in, max_iters]         (columns past steps_run are zero)
+ *   steps_run: device int32[1], number of decoder steps dynamic_decode would have run.
+ *   dropout_keep: NULL (inference: tf.layers.dropout is the identity, modules.py:27), or
+ *   device float [max_iters, B, prenet_depth1 + prenet_depth2] of 0/1 keep flags replaying a
+ *   training-mode mask; kept activations are scaled by 1/(1-0.5). */
+int taco_decode(taco_handle h, const float* enc_out, int32_t B, int32_t T_in, int32_t max_iters,
+                const float* dropout_keep, float* mel, float* align, int32_t* steps_run,
+                void* ws, size_t ws_bytes, taco_stream_t stream);
+
+/* Post-processing net: post-CBHG K=8 without sequence lengths + dense to num_freq
+ * (model/decoder.py:44-57).  mel [B,T,num_mels] -> linear [B,T,num_freq]. */
+int taco_postnet(taco_handle h, const float* mel, int32_t B, int32_t T, float* linear,
+                 void* ws, size_t ws_bytes, taco_stream_t stream);
+
+/* tools/audio.py:57-64 spectrogram_tensorflow_inv: de-normalise, dB->amplitude, ^power,
+ * then Griffin-Lim with zero initial phase (audio.py:183-205; uncentred STFT, periodic Hann
+ * on analysis and synthesis, no window-sum normalisation).  The reference inverts only
+ * linear_outputs[0] (synthesizer.py:26); here every row of the batch is inverted.
+ * linear [B,T,num_freq] -> wav [B,(T-1)*hop+win].  No de-emphasis (host, synthesizer.py:44). */
+int taco_griffin_lim(taco_handle h, const float* linear, int32_t B, int32_t T, int32_t iters,
+                     float* wav, void* ws, size_t ws_bytes, taco_stream_t stream);
+
+/* The whole session.run of synthesizer.py:39-43: encode -> decode -> postnet
+ * [-> Griffin-Lim when wav != NULL].  enc_out may be NULL (kept in the workspace). */
+int taco_synthesize(taco_handle h, const int32_t* ids, const int32_t* lens, int32_t B, int32_t T_in,
+                    int32_t max_iters, int32_t gl_iters, float* enc_out, float* mel, float* linear,
+                    float* align, float* wav, int32_t* steps_run,
+                    void* ws, size_t ws_bytes, taco_stream_t stream);
+
+/* Measurement hooks (no reference counterpart; used by bench.py for the roofline leg).
+ * taco_timing_begin(kind) makes every later launch of kernel family `kind` (see
+ * taco_kernel_name) record a HIP event pair on its stream; taco_timing_end synchronises,
+ * returns launches and summed milliseconds, and switches timing off. */
+int taco_timing_begin(taco_handle h, int32_t kind);
+int taco_timing_end(taco_handle h, int32_t* launches, double* total_ms);
+const char* taco_kernel_name(int32_t kind);
+int32_t taco_num_kernel_kinds(void);
+
+/* Selects how taco_decode issues its per-step kernels: 0 = eager launches,
+ * 1 = one captured hipGraph per (B, T_in, max_iters, buffers) replayed (default). */
+int taco_set_decode_graph(taco_handle h, int32_t enable);
+
+/* Test hook (no reference counterpart): one launch of the dense / SAME-conv1d implicit-GEMM
+ * kernel, C[m,n] = (act(sum_{j,c} X[b,t+j-padl,c] W[j*Cin+c,n] + bias[n])) * scale[n] + shift[n]
+ * + R[m,n], m = b*T + t.  All pointers are device pointers; W is [taps*Cin, ldw] with ldw a
+ * multiple of 128 (zero padded); bias/scale/shift/R may be NULL.  act: 0 none, 1 relu,
+ * 2 sigmoid, 3 tanh; pool != 0 reads max(X[t], X[t+1]) (model/modules.py:70-71). */
+int taco_debug_conv_gemm(const float* X, int32_t ldx, int32_t M, int32_t T, int32_t Cin, int32_t taps,
+                         int32_t padl, const float* W, int32_t ldw, int32_t N, const float* bias,
+                         const float* scale, const float* shift, const float* R, int32_t ldr, float* C,
+                         int32_t ldc, int32_t act, int32_t pool, taco_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TACO_H_ */

@@ -1,0 +1,298 @@
+// Decoder-step kernels: the body of dynamic_decode(BasicDecoder(output_cell, TestingHelper))
+// (model/decoder.py:18-40, model/rnn_wrappers.py:24-26,51-53, model/helpers.py:66-78;
+// step maths in SURVEY.md A.7).
+//
+// Data layout ("Q layout"): every per-step vector of the batch (previous frame, context, GRU
+// states, prenet activations, query, ...) is stored batch-minor as float4 quads,
+//     act[(k/4) * Bpad + b] = {x_b[k], x_b[k+1], x_b[k+2], x_b[k+3]},   Bpad = 16*ceil(B/16),
+// which is exactly the C/D fragment of v_mfma_f32_16x16x4_f32 when the weights are the A
+// operand and the activations the B operand (lane l: column b = l&15, rows n = 4*(l>>4)+reg),
+// and - with the K order inside a 16-deep step permuted so that MFMA i consumes
+// k = 4*(l>>4) + i - also its B operand.  Every global access is a coalesced dwordx4; the
+// weights are re-packed once (taco_create) as Wp[N/16][K/16][64 lanes][4].
+//
+// dec_gemm: one 16(n) x 16(b) tile per workgroup, K split over the 4 waves (fixed chunks,
+// fixed-order LDS reduction => results do not depend on batch size or placement), fused
+// epilogues for the prenet (ReLU [+dropout replay]), GRU gates (sigmoid, r*h, u), GRU
+// candidate (tanh, state update, residual) and the r-frame output projection (+stop test).
+#include "kernels.h"
+
+namespace taco {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float dsigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float dtanh(float x) {
+    const float e = expf(2.f * x);
+    return 1.f - 2.f / (e + 1.f);
+}
+
+__global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs a) {
+    __shared__ f32x4 red[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ntile = blockIdx.x;
+    const int b0 = blockIdx.y * 16;
+    const int nk16 = a.k16_0 + a.k16_1;
+    const int chunk = (nk16 + 3) >> 2;
+    const int ks_begin = wave * chunk;
+    const int ks_end = min(nk16, ks_begin + chunk);
+
+    const float4* Wp = reinterpret_cast<const float4*>(a.Wp) + ((size_t)ntile * nk16) * 64 + lane;
+    const int lb = b0 + (lane & 15);
+    const int lq = lane >> 4;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+        const float4 w = Wp[(size_t)ks * 64];
+        const float4* src;
+        int kl;
+        if (ks < a.k16_0) { src = reinterpret_cast<const float4*>(a.src0); kl = ks; }
+        else { src = reinterpret_cast<const float4*>(a.src1); kl = ks - a.k16_0; }
+        const float4 x = src[(size_t)(4 * kl + lq) * a.Bpad + lb];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x.w, acc1, 0, 0, 0);
+    }
+    red[wave][lane] = acc0 + acc1;
+    __syncthreads();
+    if (wave != 0) return;
+    f32x4 v = red[0][lane];
+    v += red[1][lane];
+    v += red[2][lane];
+    v += red[3][lane];
+
+    const int n = ntile * 16 + 4 * lq;                 // first of this lane's 4 output rows
+    const size_t e = (size_t)(n >> 2) * a.Bpad + lb;   // float4 index in a Q-layout buffer of dimension N
+    if (a.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    }
+    switch (a.epi) {
+        case DE_LINEAR:
+            reinterpret_cast<f32x4*>(a.out)[e] = v;
+            break;
+        case DE_RELU: {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            if (a.keep && lb < a.B) {
+                const float4 k = *reinterpret_cast<const float4*>(a.keep + (size_t)lb * a.keep_ld + n);
+                v.x *= 2.f * k.x; v.y *= 2.f * k.y; v.z *= 2.f * k.z; v.w *= 2.f * k.w;
+            }
+            reinterpret_cast<f32x4*>(a.out)[e] = v;
+            break;
+        }
+        case DE_GATES: {
+            f32x4 g;
+            g.x = dsigmoid(v.x); g.y = dsigmoid(v.y); g.z = dsigmoid(v.z); g.w = dsigmoid(v.w);
+            const int H = a.N >> 1;
+            if (n < H) {
+                const f32x4 hv = reinterpret_cast<const f32x4*>(a.h)[e];
+                reinterpret_cast<f32x4*>(a.out)[e] = g * hv;                         // r * h
+            } else {
+                reinterpret_cast<f32x4*>(a.u)[e - (size_t)(H >> 2) * a.Bpad] = g;   // u
+            }
+            break;
+        }
+        case DE_CAND: {
+            f32x4 c;
+            c.x = dtanh(v.x); c.y = dtanh(v.y); c.z = dtanh(v.z); c.w = dtanh(v.w);
+            const f32x4 u = reinterpret_cast<const f32x4*>(a.u)[e];
+            const f32x4 hv = reinterpret_cast<const f32x4*>(a.h)[e];
+            const f32x4 hn = u * hv + (1.f - u) * c;
+            reinterpret_cast<f32x4*>(a.h)[e] = hn;
+            if (a.res_out) reinterpret_cast<f32x4*>(a.res_out)[e] = hn + reinterpret_cast<const f32x4*>(a.res)[e];
+            break;
+        }
+        case DE_OUT: {
+            reinterpret_cast<f32x4*>(a.out)[e] = v;
+            if (lb < a.B && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f)) atomicOr(a.nz + lb, 1);
+            break;
+        }
+    }
+}
+
+void launch_dec_gemm(const DecGemmArgs& a, hipStream_t s, Timing* tm) {
+    if (tm) tm->begin(KK_DEC_GEMM, s);
+    hipLaunchKernelGGL(dec_gemm_kernel, dim3(a.N / 16, a.Bpad / 16), dim3(256), 0, s, a);
+    if (tm) tm->end(KK_DEC_GEMM, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// Bahdanau attention for one step (TF _bahdanau_score + softmax + context; decoder.py:20):
+//   e_t = sum_d v[d] * tanh(keys[t,d] + q[d])  over ALL T_in (no memory_sequence_length, A.8)
+//   a = softmax(e);  ctx = sum_t a_t * values[t,:]
+// One workgroup per utterance; a wave owns time steps t = wave, wave+NW, ...; each lane owns
+// d-quads lane, lane+64, ...; wave butterflies for the score sums, block reductions in LDS.
+constexpr int ATTN_THREADS = 512;
+constexpr int ATTN_WAVES = ATTN_THREADS / 64;
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+    return x;
+}
+
+__global__ __launch_bounds__(ATTN_THREADS) void dec_attention_kernel(DecAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* e = smem;                                   // [T_in]
+    float* redw = smem + ((a.T_in + 3) & ~3);          // [ATTN_WAVES] scalars
+    f32x4* cred = reinterpret_cast<f32x4*>(redw + 16); // [ATTN_WAVES][Dv/4]
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int AQ = a.A >> 2, VQ = a.Dv >> 2;
+
+    // ---- scores
+    const float4* q4 = reinterpret_cast<const float4*>(a.q);
+    const float4* v4 = reinterpret_cast<const float4*>(a.v);
+    const float4* kb = reinterpret_cast<const float4*>(a.keys) + (size_t)b * a.T_in * AQ;
+    for (int t0 = wave; t0 < a.T_in; t0 += 2 * ATTN_WAVES) {
+        const int t1 = t0 + ATTN_WAVES;
+        float s0 = 0.f, s1 = 0.f;
+        for (int dq = lane; dq < AQ; dq += 64) {
+            const float4 q = q4[(size_t)dq * a.Bpad + b];
+            const float4 vv = v4[dq];
+            const float4 k0 = kb[(size_t)t0 * AQ + dq];
+            s0 += vv.x * dtanh(k0.x + q.x) + vv.y * dtanh(k0.y + q.y) + vv.z * dtanh(k0.z + q.z) +
+                  vv.w * dtanh(k0.w + q.w);
+            if (t1 < a.T_in) {
+                const float4 k1 = kb[(size_t)t1 * AQ + dq];
+                s1 += vv.x * dtanh(k1.x + q.x) + vv.y * dtanh(k1.y + q.y) + vv.z * dtanh(k1.z + q.z) +
+                      vv.w * dtanh(k1.w + q.w);
+            }
+        }
+        s0 = wave_sum(s0);
+        s1 = wave_sum(s1);
+        if (lane == 0) {
+            e[t0] = s0;
+            if (t1 < a.T_in) e[t1] = s1;
+        }
+    }
+    __syncthreads();
+    // ---- softmax over T_in (max-subtracted, as tf.nn.softmax)
+    float mx = -INFINITY;
+    for (int t = tid; t < a.T_in; t += ATTN_THREADS) mx = fmaxf(mx, e[t]);
+    mx = wave_max(mx);
+    if (lane == 0) redw[wave] = mx;
+    __syncthreads();
+    mx = redw[0];
+#pragma unroll
+    for (int w = 1; w < ATTN_WAVES; ++w) mx = fmaxf(mx, redw[w]);
+    __syncthreads();
+    float sum = 0.f;
+    for (int t = tid; t < a.T_in; t += ATTN_THREADS) {
+        const float p = expf(e[t] - mx);
+        e[t] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) redw[wave] = sum;
+    __syncthreads();
+    sum = redw[0];
+#pragma unroll
+    for (int w = 1; w < ATTN_WAVES; ++w) sum += redw[w];
+    const float inv = 1.f / sum;
+    float* arow = a.align + (size_t)b * a.T_in;
+    for (int t = tid; t < a.T_in; t += ATTN_THREADS) {
+        const float p = e[t] * inv;
+        e[t] = p;
+        arow[t] = p;
+    }
+    __syncthreads();
+    // ---- context
+    const float4* vb = reinterpret_cast<const float4*>(a.values) + (size_t)b * a.T_in * VQ;
+    for (int dq = lane; dq < VQ; dq += 64) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int t = wave; t < a.T_in; t += ATTN_WAVES) {
+            const float4 x = vb[(size_t)t * VQ + dq];
+            const float p = e[t];
+            acc.x = fmaf(p, x.x, acc.x); acc.y = fmaf(p, x.y, acc.y);
+            acc.z = fmaf(p, x.z, acc.z); acc.w = fmaf(p, x.w, acc.w);
+        }
+        cred[wave * VQ + dq] = acc;
+    }
+    __syncthreads();
+    for (int dq = tid; dq < VQ; dq += ATTN_THREADS) {
+        f32x4 acc = cred[dq];
+#pragma unroll
+        for (int w = 1; w < ATTN_WAVES; ++w) acc += cred[w * VQ + dq];
+        reinterpret_cast<f32x4*>(a.ctx)[(size_t)dq * a.Bpad + b] = acc;
+    }
+}
+
+void launch_dec_attention(const DecAttnArgs& a, hipStream_t s, Timing* tm) {
+    if (tm) tm->begin(KK_DEC_ATTN, s);
+    const size_t shm = (size_t)(((a.T_in + 3) & ~3) + 16) * 4 + (size_t)ATTN_WAVES * (a.Dv / 4) * 16;
+    hipLaunchKernelGGL(dec_attention_kernel, dim3(a.B), dim3(ATTN_THREADS), shm, s, a);
+    if (tm) tm->end(KK_DEC_ATTN, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// Finalisation: stop test bookkeeping, [S][NR/4][Bpad][4] -> mel [B][S*NR],
+// alignS [S][B][T_in] -> align [B][T_in][S] (model/tacotron.py:51).
+__global__ void dec_steps_kernel(const int32_t* __restrict__ nz, int S, int B, int Bpad, int32_t* steps_run) {
+    // dynamic_decode: finished_b |= all(out_b == 0); stop after the step where all are finished.
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int steps = S;
+    // fin is sticky per utterance; count how many are finished so far
+    // (B is small: a serial scan costs S*B loads once per decode)
+    int nfin = 0;
+    extern __shared__ int32_t fin[];
+    for (int b = 0; b < B; ++b) fin[b] = 0;
+    for (int s = 0; s < S; ++s) {
+        for (int b = 0; b < B; ++b) {
+            if (!fin[b] && nz[(size_t)s * Bpad + b] == 0) { fin[b] = 1; ++nfin; }
+        }
+        if (nfin == B) { steps = s + 1; break; }
+    }
+    *steps_run = steps;
+}
+
+__global__ void dec_mel_kernel(const float* __restrict__ outQ, const int32_t* __restrict__ steps_run, int S, int NR,
+                               int B, int Bpad, float* __restrict__ mel) {
+    const int steps = *steps_run;
+    const long total = (long)B * S * NR;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % NR);
+        const long r = i / NR;
+        const int s = (int)(r % S);
+        const int b = (int)(r / S);
+        float v = 0.f;
+        if (s < steps) v = outQ[(((size_t)s * (NR >> 2) + (n >> 2)) * Bpad + b) * 4 + (n & 3)];
+        mel[i] = v;
+    }
+}
+
+__global__ void dec_align_kernel(const float* __restrict__ alignS, const int32_t* __restrict__ steps_run, int S, int B,
+                                 int T_in, float* __restrict__ align) {
+    const int steps = *steps_run;
+    const long total = (long)B * T_in * S;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int s = (int)(i % S);
+        const long r = i / S;
+        const int t = (int)(r % T_in);
+        const int b = (int)(r / T_in);
+        align[i] = s < steps ? alignS[((size_t)s * B + b) * T_in + t] : 0.f;
+    }
+}
+
+void launch_dec_finalize(const float* outQ, const float* alignS, const int32_t* nz, int S, int NR, int B, int Bpad,
+                         int T_in, float* mel, float* align, int32_t* steps_run, hipStream_t s, Timing* tm) {
+    if (tm) tm->begin(KK_DEC_MISC, s);
+    hipLaunchKernelGGL(dec_steps_kernel, dim3(1), dim3(64), (size_t)B * 4, s, nz, S, B, Bpad, steps_run);
+    long total = (long)B * S * NR;
+    int blocks = (int)std::min<long>(2048, (total + 255) / 256);
+    hipLaunchKernelGGL(dec_mel_kernel, dim3(blocks), dim3(256), 0, s, outQ, steps_run, S, NR, B, Bpad, mel);
+    total = (long)B * T_in * S;
+    blocks = (int)std::min<long>(2048, (total + 255) / 256);
+    hipLaunchKernelGGL(dec_align_kernel, dim3(blocks), dim3(256), 0, s, alignS, steps_run, S, B, T_in, align);
+    if (tm) tm->end(KK_DEC_MISC, s);
+}
+
+}  // namespace taco

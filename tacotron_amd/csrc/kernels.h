@@ -1,0 +1,118 @@
+// Internal declarations shared by the HIP translation units of libtaco_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace taco {
+
+// Kernel families, for taco_timing_begin / taco_kernel_name.
+enum KernelKind : int {
+    KK_CONV_GEMM = 0,   // conv_gemm_kernel<*>: dense / conv1d implicit GEMM on fp32 MFMA
+    KK_HIGHWAY,         // highway_combine_kernel
+    KK_GATHER,          // embed_gather_kernel
+    KK_BIGRU,           // bigru_scan_kernel (one launch scans all T steps)
+    KK_DEC_GEMM,        // dec_gemm_kernel: decoder-step skinny GEMM
+    KK_DEC_ATTN,        // dec_attention_kernel
+    KK_DEC_MISC,        // decoder finalisation (transposes, stop test)
+    KK_DEC_GRAPH,       // the whole captured decode loop (one hipGraphLaunch)
+    KK_GL_MAG,          // spectrogram de-normalisation
+    KK_GL_ITER,         // fused STFT -> phase -> iSTFT Griffin-Lim iteration
+    KK_GL_OLA,          // final overlap-add
+    KK_COUNT
+};
+
+// Optional event-pair recorder around launches of one kernel family.
+struct Timing {
+    int kind = -1;
+    std::vector<hipEvent_t> ev;   // pooled; pairs [2i], [2i+1]
+    size_t used = 0;
+    void begin(int k, hipStream_t s);
+    void end(int k, hipStream_t s);
+};
+
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3, ACT_HIGHWAY_SPLIT = 4 };
+
+// C[m, n] = epi( sum_{j<taps} sum_{c<Cin} X[b, t+j-padl, c] * W[j*Cin+c, n] ), m = b*T + t.
+// epi(v) = ((act(v + bias[n])) * scale[n] + shift[n]) + R[m, n]   (absent pieces skipped)
+struct GemmArgs {
+    const float* X; int ldx;
+    int M, T;
+    int Cin, taps, padl;
+    const float* W; int ldw;      // packed [taps*Cin, ldw], ldw multiple of 128, zero padded
+    int N;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    const float* R; int ldr;
+    float* C; int ldc;
+    int act;
+    int pool;                     // A operand is max(X[t], X[t+1]) (max_pooling1d 2/1 'same')
+};
+void launch_conv_gemm(const GemmArgs& a, hipStream_t s, Timing* tm);
+
+// y = H*T + x*(1-T) with HT = [relu(H) | sigmoid(T)] rows of width 2*depth
+void launch_highway_combine(const float* HT, const float* x, float* y, int M, int depth, hipStream_t s, Timing* tm);
+
+// out[m, :] = lut[clamp(ids[m]), :]  (width floats, multiple of 4)
+void launch_embed_gather(const int32_t* ids, const float* lut, float* out, int M, int width, int num_rows,
+                         hipStream_t s, Timing* tm);
+
+// Bidirectional GRU(128) scan. xp [B*T, 768] = x @ [fw gates|fw cand|bw gates|bw cand] + biases,
+// Pg/Pc the packed recurrent weights per direction; lens may be null. out [B*T, 256].
+constexpr int BIGRU_H = 128;
+constexpr int BIGRU_THREADS = 512;
+void launch_bigru_scan(const float* xp, const float* Pg, const float* Pc, const int32_t* lens, float* out,
+                       int B, int T, hipStream_t s, Timing* tm);
+
+// Decoder-step skinny GEMM on "Q layout" activations: a vector of dimension K for batch column b
+// lives at act[(k/4)*Bpad + b] as float4 {k..k+3}; Bpad is a multiple of 16.
+enum DecEpi : int { DE_LINEAR = 0, DE_RELU = 1, DE_GATES = 2, DE_CAND = 3, DE_OUT = 4 };
+struct DecGemmArgs {
+    const float* src0; int k16_0;     // first K segment (K0 = 16*k16_0)
+    const float* src1; int k16_1;     // second K segment or null/0
+    const float* Wp;                  // packed [N/16][K/16][64][4]
+    int N;
+    const float* bias;                // [N] or null
+    int epi;
+    int B, Bpad;
+    float* out;                       // LINEAR/RELU/OUT: result; GATES: r*h; CAND: unused
+    float* u;                         // GATES: writes u; CAND: reads u
+    float* h;                         // GATES: reads h; CAND: reads + updates h in place
+    const float* res; float* res_out; // CAND: res_out = h_new + res (optional)
+    const float* keep; int keep_ld;   // RELU: optional dropout keep flags [B, keep_ld] (+col offset applied)
+    int32_t* nz;                      // OUT: nz[b] |= any(out != 0)
+};
+void launch_dec_gemm(const DecGemmArgs& a, hipStream_t s, Timing* tm);
+
+struct DecAttnArgs {
+    const float* q;        // Q layout [A/4][Bpad][4]
+    const float* keys;     // [B, T_in, A]
+    const float* values;   // [B, T_in, Dv]
+    const float* v;        // [A]
+    float* ctx;            // Q layout [Dv/4][Bpad][4]
+    float* align;          // [B, T_in] row for this step (contiguous per utterance)
+    int B, Bpad, T_in, A, Dv;
+};
+void launch_dec_attention(const DecAttnArgs& a, hipStream_t s, Timing* tm);
+
+// outQ [S][NR/4][Bpad][4] -> mel [B][S*NR] (zero past steps*NR); alignS [S][B][T_in] -> align [B][T_in][S].
+void launch_dec_finalize(const float* outQ, const float* alignS, const int32_t* nz, int S, int NR, int B, int Bpad,
+                         int T_in, float* mel, float* align, int32_t* steps_run, hipStream_t s, Timing* tm);
+
+// Griffin-Lim
+struct GLPlan {
+    int n_fft, hop, win, nbins;       // 2048, 300, 1200, 1025
+    const float* twiddle;             // [n_fft] complex (cos, -sin)(2*pi*j/n_fft), float2
+    const float* window;              // [win] periodic Hann
+};
+void launch_gl_mag(const float* lin, float* mag, size_t n, float min_db, float ref_db, float power,
+                   hipStream_t s, Timing* tm);
+// frames_in/out [B*T][win]; first != 0: inverse of (mag, zero phase) only.
+void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, float* frames_out, int B, int T,
+                    int first, hipStream_t s, Timing* tm);
+void launch_gl_ola(const GLPlan& p, const float* frames, float* wav, int B, int T, hipStream_t s, Timing* tm);
+
+}  // namespace taco

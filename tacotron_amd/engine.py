@@ -1,0 +1,219 @@
+"""TacoEngine: the Python face of one libtaco_hip handle (one GPU).
+
+PyTorch-ROCm is used for exactly three things: device buffers (`torch.empty(..., device=)` +
+`.data_ptr()`), a HIP stream, and host<->device copies. All arithmetic happens inside the
+C-ABI calls (include/taco.h). Mirrors what one `tf.Session` does for the reference
+(synthesizer.py:29-43): holds the restored weights and runs the graph on fed ids."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .hparams import hparams as _default_hparams
+from .weights import check_weights
+
+
+class TacoError(RuntimeError):
+    pass
+
+
+class TacoEngine:
+    def __init__(self, weights, hp=None, device=0):
+        self.hp = hp or _default_hparams
+        self.lib = _lib.load_library()
+        if not torch.cuda.is_available():
+            raise TacoError('TacoEngine needs a GPU (torch.cuda.is_available() is False); there is no CPU path')
+        check_weights(weights, self.hp)
+        self.device = torch.device('cuda', device)
+        self._hp_struct = _lib.make_hparams_struct(self.hp)
+        names = sorted(weights)
+        arrays = [np.ascontiguousarray(weights[n], dtype=np.float32) for n in names]
+        entries = (_lib.TacoWeightEntry * len(names))()
+        for e, n, a in zip(entries, names, arrays):
+            e.name = n.encode()
+            e.data = a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+            e.ndim = a.ndim
+            for i, d in enumerate(a.shape):
+                e.dims[i] = d
+        h = ctypes.c_void_p()
+        if self.lib.taco_create(ctypes.byref(self._hp_struct), entries, len(names), device, ctypes.byref(h)) != 0:
+            raise TacoError(_lib.last_error())
+        self.handle = h
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.Stream(device=self.device)
+        self._ws = None
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            torch.cuda.synchronize(self.device)
+            self.lib.taco_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers
+    def _check(self, rc):
+        if rc != 0:
+            raise TacoError(_lib.last_error())
+
+    def _workspace(self, B, T_in, S):
+        need = int(self.lib.taco_workspace_bytes(self.handle, B, T_in, S))
+        if need == 0:
+            raise TacoError('taco_workspace_bytes rejected B=%d T_in=%d max_iters=%d' % (B, T_in, S))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _dev(self, x, dtype):
+        t = torch.as_tensor(np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x)
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def _enter(self):
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _leave(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    @property
+    def _s(self):
+        return ctypes.c_void_p(self.stream.cuda_stream)
+
+    def set_decode_graph(self, enable):
+        self._check(self.lib.taco_set_decode_graph(self.handle, int(bool(enable))))
+
+    # ---- stages (tensors in, tensors out; all on self.device)
+    def encode(self, ids, lens):
+        ids = self._dev(ids, torch.int32)
+        lens = self._dev(lens, torch.int32)
+        B, T_in = ids.shape
+        if lens.shape != (B,):
+            raise TacoError('input_lengths must have shape [B]')
+        ws = self._workspace(B, T_in, self.hp.max_iters)
+        enc = torch.empty(B, T_in, 2 * self.hp.encoder_gru_num_cells, dtype=torch.float32, device=self.device)
+        self._enter()
+        self._check(self.lib.taco_encode(self.handle, ids.data_ptr(), lens.data_ptr(), B, T_in, enc.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), self._s))
+        self._leave()
+        return enc
+
+    def decode(self, enc_out, max_iters=None, dropout_keep=None):
+        enc_out = self._dev(enc_out, torch.float32)
+        B, T_in, _ = enc_out.shape
+        S = int(max_iters or self.hp.max_iters)
+        r, M = self.hp.outputs_per_step, self.hp.num_mels
+        ws = self._workspace(B, T_in, S)
+        mel = torch.empty(B, S * r, M, dtype=torch.float32, device=self.device)
+        align = torch.empty(B, T_in, S, dtype=torch.float32, device=self.device)
+        steps = torch.zeros(1, dtype=torch.int32, device=self.device)
+        keep = None
+        if dropout_keep is not None:
+            keep = self._dev(dropout_keep, torch.float32)
+            if tuple(keep.shape) != (S, B, sum(self.hp.prenet_depths)):
+                raise TacoError('dropout_keep must be [max_iters, B, %d]' % sum(self.hp.prenet_depths))
+        self._enter()
+        self._check(self.lib.taco_decode(self.handle, enc_out.data_ptr(), B, T_in, S,
+                                         keep.data_ptr() if keep is not None else None,
+                                         mel.data_ptr(), align.data_ptr(), steps.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), self._s))
+        self._leave()
+        return mel, align, steps
+
+    def postnet(self, mel):
+        mel = self._dev(mel, torch.float32)
+        B, T, _ = mel.shape
+        S = -(-T // self.hp.outputs_per_step)
+        ws = self._workspace(B, 1, S)
+        lin = torch.empty(B, T, self.hp.num_freq, dtype=torch.float32, device=self.device)
+        self._enter()
+        self._check(self.lib.taco_postnet(self.handle, mel.data_ptr(), B, T, lin.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), self._s))
+        self._leave()
+        return lin
+
+    def griffin_lim(self, linear, iters=None):
+        linear = self._dev(linear, torch.float32)
+        squeeze = linear.dim() == 2
+        if squeeze:
+            linear = linear[None]
+        B, T, _ = linear.shape
+        iters = self.hp.griffin_lim_iters if iters is None else int(iters)
+        _, hop, win = self.hp.stft_params()
+        S = -(-T // self.hp.outputs_per_step)
+        ws = self._workspace(B, 1, S)
+        wav = torch.empty(B, (T - 1) * hop + win, dtype=torch.float32, device=self.device)
+        self._enter()
+        self._check(self.lib.taco_griffin_lim(self.handle, linear.data_ptr(), B, T, iters, wav.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), self._s))
+        self._leave()
+        return wav[0] if squeeze else wav
+
+    def synthesize(self, ids, lens, max_iters=None, to_wav=False, gl_iters=None, out=None):
+        """encode -> decode -> postnet [-> Griffin-Lim] in one C call. Returns a dict of device
+        tensors; `steps` is read back (one int) to trim outputs if the stop test fired.
+        `out` may hold preallocated tensors from a previous call (bench loop)."""
+        ids = self._dev(ids, torch.int32)
+        lens = self._dev(lens, torch.int32)
+        B, T_in = ids.shape
+        S = int(max_iters or self.hp.max_iters)
+        r, M = self.hp.outputs_per_step, self.hp.num_mels
+        T = S * r
+        _, hop, win = self.hp.stft_params()
+        ws = self._workspace(B, T_in, S)
+        o = out or {}
+        def buf(name, shape, dtype=torch.float32):
+            t = o.get(name)
+            if t is None or tuple(t.shape) != tuple(shape):
+                t = torch.empty(*shape, dtype=dtype, device=self.device)
+                o[name] = t
+            return t
+        enc = buf('enc_out', (B, T_in, 2 * self.hp.encoder_gru_num_cells))
+        mel = buf('mel', (B, T, M))
+        lin = buf('linear', (B, T, self.hp.num_freq))
+        align = buf('alignments', (B, T_in, S))
+        steps = buf('steps', (1,), torch.int32)
+        wav = buf('wav', (B, (T - 1) * hop + win)) if to_wav else None
+        gl = self.hp.griffin_lim_iters if gl_iters is None else int(gl_iters)
+        self._enter()
+        self._check(self.lib.taco_synthesize(self.handle, ids.data_ptr(), lens.data_ptr(), B, T_in, S, gl,
+                                             enc.data_ptr(), mel.data_ptr(), lin.data_ptr(), align.data_ptr(),
+                                             wav.data_ptr() if wav is not None else None, steps.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), self._s))
+        self._leave()
+        return o
+
+    def finish(self, o, to_wav=False, gl_iters=None):
+        """Host-side check of the stop test (helpers.py:75): if dynamic_decode would have stopped
+        early, trim and redo the length-dependent stages on the shorter mel."""
+        steps = int(o['steps'].item())
+        S = o['alignments'].shape[2]
+        if steps < S:
+            r = self.hp.outputs_per_step
+            o = dict(o)
+            o['mel'] = o['mel'][:, :steps * r].contiguous()
+            o['alignments'] = o['alignments'][:, :, :steps].contiguous()
+            o['linear'] = self.postnet(o['mel'])
+            if to_wav:
+                o['wav'] = self.griffin_lim(o['linear'], gl_iters)
+        o['steps_run'] = steps
+        return o
+
+    # ---- measurement hooks
+    def kernel_kinds(self):
+        n = self.lib.taco_num_kernel_kinds()
+        return [self.lib.taco_kernel_name(i).decode() for i in range(n)]
+
+    def timing_begin(self, kind):
+        kinds = self.kernel_kinds()
+        self._check(self.lib.taco_timing_begin(self.handle, kinds.index(kind) if isinstance(kind, str) else kind))
+
+    def timing_end(self):
+        n = ctypes.c_int32()
+        ms = ctypes.c_double()
+        self._check(self.lib.taco_timing_end(self.handle, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value

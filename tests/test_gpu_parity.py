@@ -1,0 +1,245 @@
+"""GPU parity tests: every stage of the HIP path, called through the C ABI (TacoEngine is a
+ctypes shim), against the fp64 numpy oracle on the same seeded inputs.
+
+Tolerances: north_star asks for mel / linear within 1e-3 relative L1 of the reference and an
+identical per-frame attention argmax. Stage tests feed the ORACLE's output of the previous
+stage so each stage is judged alone, at 1e-4; the end-to-end test uses the stated 1e-3.
+With random-init weights the attention is almost flat, so the argmax is compared wherever the
+oracle's top-1/top-2 margin exceeds fp32 resolution (1e-6 absolute on probabilities ~1/T_in)
+and on a peaked-attention weight set everywhere.
+"""
+import numpy as np
+import pytest
+
+from oracle import taco_oracle as O
+from tests.util import rel_l1, max_abs, synth_ids
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize('M,T,Cin,taps,N,act,pool,extras', [
+    (95, 95, 256, 1, 256, 1, 0, False),
+    (150, 50, 128, 16, 128, 1, 0, True),
+    (64, 64, 80, 8, 128, 1, 0, True),
+    (300, 100, 2048, 3, 128, 1, 1, True),
+    (77, 11, 256, 1, 1025, 0, 0, False),
+    (1000, 250, 1024, 3, 256, 1, 1, True),
+    (4096, 512, 128, 5, 384, 0, 0, True),
+])
+def test_conv_gemm_kernel(engine, M, T, Cin, taps, N, act, pool, extras):
+    """conv_gemm vs fp64 numpy: dense, even/odd-width SAME convs, pooled loader, BN/residual epilogue,
+    N not a multiple of the tile (1025), both tile configurations."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(M + N + taps)
+    B = M // T
+    x = rng.standard_normal((B, T, Cin)).astype(np.float32)
+    w = (rng.standard_normal((taps, Cin, N)) / np.sqrt(taps * Cin)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, N).astype(np.float32) if extras else None
+    shift = rng.standard_normal(N).astype(np.float32) if extras else None
+    res = rng.standard_normal((B, T, N)).astype(np.float32) if extras else None
+    xin = O.maxpool2_same(x.astype(np.float64)) if pool else x.astype(np.float64)
+    ref = O.conv1d_same(xin, w.astype(np.float64), bias.astype(np.float64))
+    if act == 1:
+        ref = np.maximum(ref, 0)
+    if extras:
+        ref = ref * scale + shift + res
+    ldw = (N + 127) // 128 * 128
+    wp = np.zeros((taps * Cin, ldw), np.float32)
+    wp[:, :N] = w.reshape(taps * Cin, N)
+    dev = engine.device
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if a is not None else None
+    X, W, Bi, Sc, Sh, R = d(x), d(wp), d(bias), d(scale), d(shift), d(res)
+    C = torch.zeros(M, N, dtype=torch.float32, device=dev)
+    p = lambda t: t.data_ptr() if t is not None else None
+    rc = engine.lib.taco_debug_conv_gemm(p(X), Cin, M, T, Cin, taps, (taps - 1) // 2, p(W), ldw, N, p(Bi), p(Sc),
+                                         p(Sh), p(R), N, p(C), N, act, pool, None)
+    assert rc == 0, engine.lib.taco_last_error()
+    torch.cuda.synchronize()
+    got = _np(C).reshape(B, T, N)
+    assert rel_l1(got, ref) < 2e-6, rel_l1(got, ref)
+    assert max_abs(got, ref) < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('B,T_in', [(1, 5), (2, 7), (3, 37), (5, 150)])
+def test_encode(engine, hp, weights, B, T_in):
+    rng = np.random.default_rng(10 * B + T_in)
+    ids, lens = synth_ids(rng, B, T_in)
+    ref = O.encode(ids, lens, O.cast_weights(weights, np.float64), hp)
+    got = _np(engine.encode(ids, lens))
+    assert got.shape == ref.shape
+    # padded steps of the BiGRU are exactly zero (A.6)
+    for b in range(B):
+        assert np.all(got[b, lens[b]:] == 0)
+    assert rel_l1(got, ref) < 1e-4, rel_l1(got, ref)
+
+
+def _check_decode(engine, hp, w, enc, S, tag):
+    w64 = O.cast_weights(w, np.float64)
+    mel_r, al_r, steps_r = O.decode(enc, w64, hp, max_iters=S)
+    mel, al, steps = engine.decode(enc.astype(np.float32), max_iters=S)
+    mel, al, steps = _np(mel), _np(al), int(_np(steps)[0])
+    assert steps == steps_r == S
+    assert mel.shape == mel_r.shape and al.shape == al_r.shape
+    e_mel, e_al = rel_l1(mel, mel_r), rel_l1(al, al_r)
+    # argmax over T_in per (utterance, step)
+    top = np.sort(al_r, axis=1)
+    margin = top[:, -1, :] - top[:, -2, :]
+    same = al.argmax(1) == al_r.argmax(1)
+    decided = margin > 1e-6
+    print('%s: mel relL1 %.2e align relL1 %.2e argmax same %d/%d (decided %d, min margin %.2e)' % (
+        tag, e_mel, e_al, same.sum(), same.size, decided.sum(), margin.min()))
+    assert e_mel < 1e-4 and e_al < 1e-4
+    assert np.all(same[decided])
+    assert np.allclose(al.sum(1), 1.0, atol=1e-5)
+    return same, decided
+
+
+@pytest.mark.parametrize('B,T_in,S', [(1, 6, 3), (2, 9, 6), (5, 37, 12), (17, 150, 8), (32, 150, 4)])
+def test_decode(engine, hp, weights, B, T_in, S):
+    rng = np.random.default_rng(B * 1000 + T_in)
+    enc = (0.5 * rng.standard_normal((B, T_in, 256))).astype(np.float32).astype(np.float64)
+    _check_decode(engine, hp, weights, enc, S, 'decode B=%d T_in=%d S=%d' % (B, T_in, S))
+
+
+def test_decode_peaked_attention(hp):
+    """A weight set whose attention_v is scaled so the alignment is sharply peaked: the argmax
+    must then match the oracle on every frame."""
+    from tacotron_amd.engine import TacoEngine
+    from tacotron_amd.weights import init_weights
+    w = init_weights(hp, seed=7, randomize_bn=True, randomize_bias=True, attention_sharpness=40.0)
+    eng = TacoEngine(w, hp)
+    try:
+        rng = np.random.default_rng(5)
+        enc = rng.standard_normal((4, 50, 256)).astype(np.float32).astype(np.float64)
+        same, decided = _check_decode(eng, hp, w, enc, 20, 'peaked')
+        assert decided.mean() > 0.9
+        assert np.all(same)
+    finally:
+        eng.close()
+
+
+def test_decode_eager_equals_graph(engine, hp):
+    """The captured hipGraph replay and the eager launch sequence are the same kernels: bit-equal."""
+    import torch
+    rng = np.random.default_rng(3)
+    enc = rng.standard_normal((3, 20, 256)).astype(np.float32)
+    engine.set_decode_graph(True)
+    m1, a1, _ = engine.decode(enc, max_iters=7)
+    m1b, a1b, _ = engine.decode(enc, max_iters=7)
+    engine.set_decode_graph(False)
+    m2, a2, _ = engine.decode(enc, max_iters=7)
+    engine.set_decode_graph(True)
+    assert torch.equal(m1, m2) and torch.equal(a1, a2) and torch.equal(m1, m1b)
+
+
+def test_decode_batch_invariance(engine, hp):
+    """an utterance's result must not depend on what else is in the batch / shard."""
+    import torch
+    rng = np.random.default_rng(4)
+    enc = rng.standard_normal((19, 33, 256)).astype(np.float32)
+    m_all, a_all, _ = engine.decode(enc, max_iters=5)
+    for lo, hi in [(0, 1), (3, 10), (16, 19)]:
+        m, a, _ = engine.decode(enc[lo:hi], max_iters=5)
+        assert torch.equal(m, m_all[lo:hi]) and torch.equal(a, a_all[lo:hi])
+
+
+def test_decode_dropout_replay(engine, hp, weights):
+    """Optional training-mode prenet dropout replay (A.3): keep flags in, oracle applies the same."""
+    rng = np.random.default_rng(8)
+    B, T_in, S = 3, 11, 4
+    enc = rng.standard_normal((B, T_in, 256))
+    keep = (rng.random((S, B, 384)) >= 0.5).astype(np.float32)
+    w = O.cast_weights(weights, np.float64)
+    # oracle with masks: restate the loop with the mask applied after each prenet ReLU
+    from oracle.taco_oracle import _ATTW, _CELL0, _DEC, gru_cell, dense
+    keys = enc @ w['memory_layer/kernel']
+    h_att = np.zeros((B, 256)); ctx = np.zeros((B, 256)); h1 = np.zeros((B, 256)); h2 = np.zeros((B, 256))
+    prev = np.zeros((B, 80)); outs = []
+    for s in range(S):
+        x = np.concatenate([prev, ctx], -1)
+        sc = _ATTW + 'decoder_prenet_wrapper/decoder_prenet/prenet_dense_%d/'
+        x = dense(x, w[sc % 1 + 'kernel'], w[sc % 1 + 'bias'], 'relu') * keep[s, :, :256] * 2.0
+        x = dense(x, w[sc % 2 + 'kernel'], w[sc % 2 + 'bias'], 'relu') * keep[s, :, 256:] * 2.0
+        h_att = gru_cell(x, h_att, w, _ATTW + 'decoder_prenet_wrapper/gru_cell/')
+        q = h_att @ w[_ATTW + 'bahdanau_attention/query_layer/kernel']
+        e = np.sum(w[_ATTW + 'bahdanau_attention/attention_v'] * np.tanh(keys + q[:, None]), -1)
+        a = np.exp(e - e.max(-1, keepdims=True)); a /= a.sum(-1, keepdims=True)
+        ctx = np.einsum('bt,btd->bd', a, enc)
+        d0 = np.concatenate([h_att, ctx], -1) @ w[_CELL0 + 'kernel'] + w[_CELL0 + 'bias']
+        h1 = gru_cell(d0, h1, w, _DEC + 'multi_rnn_cell/cell_1/gru_cell/'); o1 = h1 + d0
+        h2 = gru_cell(o1, h2, w, _DEC + 'multi_rnn_cell/cell_2/gru_cell/'); o2 = h2 + o1
+        out = o2 @ w[_DEC + 'kernel'] + w[_DEC + 'bias']
+        outs.append(out); prev = out[:, -80:]
+    ref = np.stack(outs, 1).reshape(B, S * 5, 80)
+    mel, _, _ = engine.decode(enc.astype(np.float32), max_iters=S, dropout_keep=keep)
+    assert rel_l1(_np(mel), ref) < 1e-4
+
+
+def test_decode_stop_test(hp):
+    """helpers.py:75: with all-zero output projection every step emits exactly 0.0, so
+    dynamic_decode stops after the first step; outputs past it are zero."""
+    from tacotron_amd.engine import TacoEngine
+    from tacotron_amd.weights import init_weights
+    w = init_weights(hp, seed=3)
+    w['decoder/output_projection_wrapper/kernel'][:] = 0
+    w['decoder/output_projection_wrapper/bias'][:] = 0
+    eng = TacoEngine(w, hp)
+    try:
+        enc = np.random.default_rng(0).standard_normal((2, 9, 256)).astype(np.float32)
+        mel, al, steps = eng.decode(enc, max_iters=6)
+        assert int(_np(steps)[0]) == 1
+        _, al_r, steps_r = O.decode(enc.astype(np.float64), O.cast_weights(w, np.float64), hp, max_iters=6)
+        assert steps_r == 1
+        assert np.all(_np(mel) == 0)
+        assert rel_l1(_np(al)[:, :, :1], al_r) < 1e-4 and np.all(_np(al)[:, :, 1:] == 0)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize('B,T', [(1, 5), (2, 15), (3, 100), (2, 1000)])
+def test_postnet(engine, hp, weights, B, T):
+    rng = np.random.default_rng(B + T)
+    mel = (0.3 * rng.standard_normal((B, T, 80))).astype(np.float32)
+    ref = O.postnet(mel.astype(np.float64), O.cast_weights(weights, np.float64), hp)
+    got = _np(engine.postnet(mel))
+    assert got.shape == ref.shape
+    assert rel_l1(got, ref) < 1e-4, rel_l1(got, ref)
+
+
+@pytest.mark.parametrize('B,T,iters', [(1, 4, 0), (1, 7, 1), (2, 12, 3), (1, 40, 60)])
+def test_griffin_lim(engine, hp, B, T, iters):
+    """Griffin-Lim vs the fp64 oracle. The phase projection E/|E| is ill-conditioned where |E| is
+    tiny, so fp32 round-off grows with the iteration count; the fp32 oracle's own distance from the
+    fp64 one is printed as the noise floor, and the bound is on relative L2."""
+    rng = np.random.default_rng(T + iters)
+    lin = rng.uniform(0.3, 1.0, size=(B, T, 1025)).astype(np.float32)
+    ref = O.spectrogram_tensorflow_inv(lin.astype(np.float64), hp, iters=iters)
+    ref32 = O.spectrogram_tensorflow_inv(lin, hp, iters=iters, dtype=np.float32)
+    got = _np(engine.griffin_lim(lin, iters=iters))
+    assert got.shape == ref.shape == (B, (T - 1) * 300 + 1200)
+    l2 = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    print('GL T=%d iters=%d: gpu-vs-f64 relL2 %.2e ; f32-numpy-vs-f64 %.2e' % (T, iters, l2(got, ref), l2(ref32, ref)))
+    assert l2(got, ref) < (1e-5 if iters <= 1 else 1e-3)
+
+
+def test_synthesize_end_to_end(engine, hp, weights):
+    """ids -> mel, linear, alignments through taco_synthesize vs the oracle end to end (1e-3, north_star)."""
+    rng = np.random.default_rng(42)
+    B, T_in, S = 3, 23, 10
+    ids, lens = synth_ids(rng, B, T_in)
+    ref = O.tacotron_forward(ids, lens, weights, hp, max_iters=S)
+    o = engine.finish(engine.synthesize(ids, lens, max_iters=S, to_wav=True, gl_iters=2), to_wav=True, gl_iters=2)
+    assert o['steps_run'] == S
+    assert rel_l1(_np(o['enc_out']), ref['enc_out']) < 1e-3
+    assert rel_l1(_np(o['mel']), ref['mel']) < 1e-3
+    assert rel_l1(_np(o['linear']), ref['linear']) < 1e-3
+    assert rel_l1(_np(o['alignments']), ref['alignments']) < 1e-3
+    wav_ref = O.spectrogram_tensorflow_inv(ref['linear'], hp, iters=2)
+    assert _np(o['wav']).shape == wav_ref.shape
+    assert np.linalg.norm(_np(o['wav']) - wav_ref) / np.linalg.norm(wav_ref) < 1e-3
