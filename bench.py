@@ -1,0 +1,245 @@
+#!/usr/bin/env python
+"""bench.py - headline benchmark of the MI355X Tacotron synthesis path.
+
+Metric (BASELINE.json): mel frames/sec, whole job. Workload at N=1 = BASELINE.json configs[1]:
+batched inference B=32 per GPU, synthetic 150-character inputs, fp32, LJSpeech default hparams
+(r=5, max_iters=200 -> 1000 mel frames per utterance), outputs mel + linear spectrogram.
+A "step" is one pass of the hot path (taco_synthesize: encode -> 200-step decode -> post-net)
+over one batch whose ids are already resident in HBM. With N>1 every rank runs its own shard of
+32 utterances (weak scaling, no collective on the data path); value = all ranks' frames / max-rank time.
+
+Extra objects on the JSON line:
+  roofline     - the kernel family with the largest share of the step, timed with HIP event pairs on the
+                 engine's stream in a separate instrumented pass (taco_timing_begin/end); algorithmic bytes or
+                 flops per launch from DESIGN.md's formulas.
+  cpu_baseline - the fp32 numpy oracle ("port") timed on this host on a bounded sample of the same workload.
+  kernels      - per-family launches / ms of one instrumented step (all families).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3  # dense fp32 matrix peak (= vector peak)
+
+
+def conv_gemm_flops(hp, B, T_in, S):
+    """Exact MACs*2 of every conv_gemm launch of one step (encoder, keys, post-net, linear dense)."""
+    r, M = hp.outputs_per_step, hp.num_mels
+    T = S * r
+
+    def cbhg(rows, cin, K, bank, p1, p2, hw_depth, n_hw, gru, width):
+        f = 0
+        for k in range(1, K + 1):
+            f += 2 * rows * k * cin * bank
+        f += 2 * rows * width * K * bank * p1
+        f += 2 * rows * width * p1 * p2
+        if p2 != hw_depth:
+            f += 2 * rows * p2 * hw_depth
+        f += n_hw * 2 * rows * hw_depth * 2 * hw_depth
+        f += 2 * rows * hw_depth * 6 * gru
+        return f
+
+    enc = cbhg(B * T_in, hp.prenet_depths[1], hp.encoder_K, hp.encoder_bank_num_filters,
+               hp.encoder_proj_num_filters[0], hp.encoder_proj_num_filters[1], hp.encoder_highway_depth,
+               hp.encoder_num_highway_layers, hp.encoder_gru_num_cells, hp.encoder_proj_filter_width)
+    keys = 2 * B * T_in * 2 * hp.encoder_gru_num_cells * hp.attention_depth
+    post = cbhg(B * T, M, hp.decoder_K, hp.decoder_bank_num_filters, hp.decoder_proj_num_filters[0],
+                hp.decoder_proj_num_filters[1], hp.decoder_highway_depth, hp.decoder_num_highway_layers,
+                hp.decoder_gru_num_cells, hp.decoder_proj_filter_width)
+    lin = 2 * B * T * 2 * hp.decoder_gru_num_cells * hp.num_freq
+    return enc + keys + post + lin
+
+
+def decoder_step_bytes(hp, B, T_in):
+    """W_step (all decoder-loop parameters, fp32) + per-utterance keys+values."""
+    from tacotron_amd.weights import variable_specs
+    w = sum(int(np.prod(s)) for n, s, _ in variable_specs(hp) if n.startswith('decoder/')) * 4
+    attn = B * 2 * T_in * 2 * hp.encoder_gru_num_cells * 4
+    return w, attn
+
+
+def family_work(hp, B, T_in, S):
+    """Algorithmic work of ONE step per kernel family: (bound, amount) with amount in bytes or flops."""
+    r = hp.outputs_per_step
+    T = S * r
+    w_step, attn = decoder_step_bytes(hp, B, T_in)
+    v_bytes = hp.attention_depth * 4
+    G = hp.encoder_gru_num_cells
+    rows = B * T_in + B * T
+    _, hop, win = hp.stft_params()
+    L = (T - 1) * hop + win
+    return {
+        'conv_gemm': ('mfma', conv_gemm_flops(hp, B, T_in, S)),
+        'dec_gemm': ('hbm', (w_step - v_bytes) * S),
+        'dec_attention': ('hbm', (attn + v_bytes) * S),
+        'decode_graph': ('hbm', (w_step + attn) * S),
+        # scan: reads the hoisted input projections, writes the outputs, loads its recurrent weights once per WG
+        'bigru_scan': ('hbm', rows * (6 * G + 2 * G) * 4 + 2 * B * 2 * (3 * G * G) * 4),
+        'highway_combine': ('hbm', 4 * rows * (2 * 128 + 128 + 128) * 4),
+        'embed_gather': ('hbm', B * T_in * 128 * 4 * 2),
+        'dec_finalize': ('hbm', 2 * (B * T * hp.num_mels + B * T_in * S) * 4),
+        'gl_mag': ('hbm', 2 * B * T * hp.num_freq * 4),
+        'gl_iter': ('hbm', (hp.griffin_lim_iters + 1) * B * (T * hp.num_freq + 2 * L) * 4),
+        'gl_ola': ('hbm', B * (T * win + L) * 4),
+    }
+
+
+def cpu_baseline(hp, weights, T_in, S, budget_s=20.0):
+    """fp32 numpy restatement (oracle/taco_oracle.py) on this host's cores: full hot path
+    (encode -> decode -> post-net) on a bounded sample of the workload."""
+    from oracle import taco_oracle as O
+    from tests.util import synth_ids
+    try:
+        from threadpoolctl import threadpool_info
+        thr = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        thr = os.cpu_count() or 1
+    w32 = O.cast_weights(weights, np.float32)
+    B = 8
+    ids, lens = synth_ids(np.random.default_rng(0), B, T_in, ragged=False)
+    run = lambda: O.postnet(O.decode(O.encode(ids, lens, w32, hp), w32, hp, max_iters=S)[0], w32, hp)
+    run()  # warm-up (BLAS thread pools, page faults)
+    n, t0 = 0, time.time()
+    while True:
+        run()
+        n += 1
+        el = time.time() - t0
+        if el > budget_s or n >= 5:
+            break
+    frames = n * B * S * hp.outputs_per_step
+    return {'value': frames / el, 'unit': 'mel frames/s', 'cores': int(thr), 'kind': 'port',
+            'sample': '%d x (B=%d utterances, T_in=%d, %d decoder steps, mel+linear), fp32 numpy oracle, %.1f s'
+                      % (n, B, T_in, S, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
+    ap.add_argument('--t-in', type=int, default=150)
+    ap.add_argument('--max-iters', type=int, default=200)
+    ap.add_argument('--to-wav', action='store_true', help='include the 60-iteration Griffin-Lim (configs[2])')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tacotron_amd.engine import TacoEngine
+    from tacotron_amd.hparams import HParams
+    from tacotron_amd.weights import init_weights
+    from tests.util import synth_ids
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    hp = HParams()
+    hp.max_iters = args.max_iters
+    weights = init_weights(hp, seed=1234)          # "random-init weights" (BASELINE.json configs)
+    eng = TacoEngine(weights, hp, device=local)
+    B, T_in, S = args.batch, args.t_in, args.max_iters
+    # this rank's shard of the synthetic job: utterances [rank*B, (rank+1)*B)
+    ids_all, lens_all = synth_ids(np.random.default_rng(0), B * world, T_in, ragged=False)
+    ids = torch.from_numpy(ids_all[rank * B:(rank + 1) * B]).to(eng.device)
+    lens = torch.from_numpy(lens_all[rank * B:(rank + 1) * B]).to(eng.device)
+    out = {}
+
+    def step():
+        eng.synthesize(ids, lens, max_iters=S, to_wav=args.to_wav, out=out)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    steps_run = int(out['steps'].item())
+    frames_per_step = world * B * steps_run * hp.outputs_per_step
+    value = frames_per_step * args.steps / el
+
+    res = {
+        'metric': 'mel frames/sec (whole job)', 'value': value, 'unit': 'mel frames/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * el / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic (seeded character ids, random-init weights with TF default initialisers)',
+        'config': {'workload': 'BASELINE.json configs[1]: batched inference B=%d per GPU, %d-char inputs, fp32, '
+                               'max_iters=%d r=%d, outputs mel+linear%s' % (
+                                   B, T_in, S, hp.outputs_per_step,
+                                   ' + 60-iter Griffin-Lim wav' if args.to_wav else ''),
+                   'batch_per_gpu': B, 'global_batch': B * world, 'T_in': T_in, 'max_iters': S,
+                   'frames_per_utterance': steps_run * hp.outputs_per_step, 'parallelism': 'utterance-sharded x%d' % world},
+        'p50_batch_latency_ms': 1e3 * el / args.steps,
+    }
+
+    if rank == 0 and not args.no_roofline:
+        work = family_work(hp, B, T_in, S)
+        kinds = eng.kernel_kinds()
+        fam = {}
+        for k in kinds:
+            if k == 'decode_graph':
+                continue
+            eng.timing_begin(k)
+            step()
+            n, ms = eng.timing_end()
+            if n:
+                fam[k] = {'launches': n, 'ms': ms, 'avg_us': 1e3 * ms / n}
+        eng.timing_begin('decode_graph')
+        step()
+        n, ms = eng.timing_end()
+        if n:
+            fam['decode_graph'] = {'launches': n, 'ms': ms, 'avg_us': 1e3 * ms / n}
+        res['kernels'] = fam
+        leaf = {k: v for k, v in fam.items() if k != 'decode_graph'}
+        dom = max(leaf, key=lambda k: leaf[k]['ms'])
+        bound, amount = work[dom]
+        per_launch = amount / leaf[dom]['launches']
+        sec = leaf[dom]['ms'] * 1e-3 / leaf[dom]['launches']
+        if bound == 'hbm':
+            ach, peak, unit = per_launch / sec / 1e9, HBM_PEAK_GBS, 'GB/s'
+        else:
+            ach, peak, unit = per_launch / sec / 1e12, FP32_MFMA_PEAK_TF, 'TFLOP/s'
+        res['roofline'] = {'kernel': dom, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit,
+                           'frac': ach / peak, 'traffic': None, 'launches_per_step': leaf[dom]['launches'],
+                           'avg_launch_us': 1e6 * sec, 'algorithmic_per_launch': per_launch}
+        if 'decode_graph' in fam:
+            b, amt = work['decode_graph']
+            s2 = fam['decode_graph']['ms'] * 1e-3
+            res['decode_loop'] = {'ms': fam['decode_graph']['ms'], 'us_per_decoder_step': 1e6 * s2 / S,
+                                  'achieved_GBps': amt / s2 / 1e9, 'frac_of_hbm': amt / s2 / 1e9 / HBM_PEAK_GBS}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline(hp, weights, T_in, S)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == '__main__':
+    main()

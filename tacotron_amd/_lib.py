@@ -43,6 +43,9 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError('%s is missing: build it with `python -m tacotron_amd.build` '
                            '(there is no CPU fallback)' % LIB_PATH)
+    # torch first: it ships its own libamdhip64.so.7, and the stream / device pointers it hands us are
+    # only meaningful to that copy of the HIP runtime. Loaded afterwards, libtaco_hip.so binds to it by soname.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_size_t
     lib.taco_last_error.restype = ctypes.c_char_p

@@ -11,7 +11,7 @@
 // k = 4*(l>>4) + i - also its B operand.  Every global access is a coalesced dwordx4; the
 // weights are re-packed once (taco_create) as Wp[N/16][K/16][64 lanes][4].
 //
-// dec_gemm: one 16(n) x 16(b) tile per workgroup, K split over the 4 waves (fixed chunks,
+// dec_gemm: one 16(n) x 16(b) tile per workgroup, K split over the 8 waves (fixed chunks,
 // fixed-order LDS reduction => results do not depend on batch size or placement), fused
 // epilogues for the prenet (ReLU [+dropout replay]), GRU gates (sigmoid, r*h, u), GRU
 // candidate (tanh, state update, residual) and the r-frame output projection (+stop test).
@@ -27,41 +27,56 @@ __device__ __forceinline__ float dtanh(float x) {
     return 1.f - 2.f / (e + 1.f);
 }
 
-__global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs a) {
-    __shared__ f32x4 red[4][64];
+constexpr int DG_WAVES = 8;       // K is split over 8 waves (fixed chunks => fixed summation order)
+constexpr int DG_THREADS = 64 * DG_WAVES;
+constexpr int DG_DEPTH = 4;       // k16-steps whose loads are issued together per wave
+
+__global__ __launch_bounds__(DG_THREADS) void dec_gemm_kernel(DecGemmArgs a) {
+    __shared__ f32x4 red[DG_WAVES][64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int ntile = blockIdx.x;
     const int b0 = blockIdx.y * 16;
     const int nk16 = a.k16_0 + a.k16_1;
-    const int chunk = (nk16 + 3) >> 2;
+    const int chunk = (nk16 + DG_WAVES - 1) / DG_WAVES;
     const int ks_begin = wave * chunk;
     const int ks_end = min(nk16, ks_begin + chunk);
 
     const float4* Wp = reinterpret_cast<const float4*>(a.Wp) + ((size_t)ntile * nk16) * 64 + lane;
+    const float4* s0 = reinterpret_cast<const float4*>(a.src0);
+    const float4* s1 = reinterpret_cast<const float4*>(a.src1);
     const int lb = b0 + (lane & 15);
     const int lq = lane >> 4;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int ks = ks_begin; ks < ks_end; ++ks) {
-        const float4 w = Wp[(size_t)ks * 64];
-        const float4* src;
-        int kl;
-        if (ks < a.k16_0) { src = reinterpret_cast<const float4*>(a.src0); kl = ks; }
-        else { src = reinterpret_cast<const float4*>(a.src1); kl = ks - a.k16_0; }
-        const float4 x = src[(size_t)(4 * kl + lq) * a.Bpad + lb];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x.w, acc1, 0, 0, 0);
+    for (int base = ks_begin; base < ks_end; base += DG_DEPTH) {
+        float4 w[DG_DEPTH], x[DG_DEPTH];
+        // all loads of this group are issued before the first MFMA waits on one
+#pragma unroll
+        for (int i = 0; i < DG_DEPTH; ++i) {
+            const int ks = base + i;
+            if (ks < ks_end) {
+                w[i] = Wp[(size_t)ks * 64];
+                x[i] = ks < a.k16_0 ? s0[(size_t)(4 * ks + lq) * a.Bpad + lb]
+                                    : s1[(size_t)(4 * (ks - a.k16_0) + lq) * a.Bpad + lb];
+            } else {
+                w[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DG_DEPTH; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, x[i].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].y, x[i].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, x[i].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, x[i].w, acc1, 0, 0, 0);
+        }
     }
     red[wave][lane] = acc0 + acc1;
     __syncthreads();
     if (wave != 0) return;
     f32x4 v = red[0][lane];
-    v += red[1][lane];
-    v += red[2][lane];
-    v += red[3][lane];
+#pragma unroll
+    for (int w = 1; w < DG_WAVES; ++w) v += red[w][lane];
 
     const int n = ntile * 16 + 4 * lq;                 // first of this lane's 4 output rows
     const size_t e = (size_t)(n >> 2) * a.Bpad + lb;   // float4 index in a Q-layout buffer of dimension N
@@ -114,7 +129,7 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs a) {
 
 void launch_dec_gemm(const DecGemmArgs& a, hipStream_t s, Timing* tm) {
     if (tm) tm->begin(KK_DEC_GEMM, s);
-    hipLaunchKernelGGL(dec_gemm_kernel, dim3(a.N / 16, a.Bpad / 16), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(dec_gemm_kernel, dim3(a.N / 16, a.Bpad / 16), dim3(DG_THREADS), 0, s, a);
     if (tm) tm->end(KK_DEC_GEMM, s);
 }
 
@@ -124,8 +139,9 @@ void launch_dec_gemm(const DecGemmArgs& a, hipStream_t s, Timing* tm) {
 //   a = softmax(e);  ctx = sum_t a_t * values[t,:]
 // One workgroup per utterance; a wave owns time steps t = wave, wave+NW, ...; each lane owns
 // d-quads lane, lane+64, ...; wave butterflies for the score sums, block reductions in LDS.
-constexpr int ATTN_THREADS = 512;
+constexpr int ATTN_THREADS = 1024;
 constexpr int ATTN_WAVES = ATTN_THREADS / 64;
+constexpr int ATTN_DEPTH = 5;     // time steps per wave whose loads are in flight together
 
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
@@ -140,80 +156,82 @@ __device__ __forceinline__ float wave_max(float x) {
 
 __global__ __launch_bounds__(ATTN_THREADS) void dec_attention_kernel(DecAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* e = smem;                                   // [T_in]
-    float* redw = smem + ((a.T_in + 3) & ~3);          // [ATTN_WAVES] scalars
-    f32x4* cred = reinterpret_cast<f32x4*>(redw + 16); // [ATTN_WAVES][Dv/4]
+    float* e = smem;                                                  // [T_in]
+    f32x4* cred = reinterpret_cast<f32x4*>(smem + ((a.T_in + 3) & ~3)); // [ATTN_WAVES][Dv/4]
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int AQ = a.A >> 2, VQ = a.Dv >> 2;
 
-    // ---- scores
+    // ---- scores: wave owns t = wave + 16*j; lane owns d-quads lane, lane+64, ...
     const float4* q4 = reinterpret_cast<const float4*>(a.q);
     const float4* v4 = reinterpret_cast<const float4*>(a.v);
     const float4* kb = reinterpret_cast<const float4*>(a.keys) + (size_t)b * a.T_in * AQ;
-    for (int t0 = wave; t0 < a.T_in; t0 += 2 * ATTN_WAVES) {
-        const int t1 = t0 + ATTN_WAVES;
-        float s0 = 0.f, s1 = 0.f;
+    for (int tb = wave; tb < a.T_in; tb += ATTN_WAVES * ATTN_DEPTH) {
+        float sc[ATTN_DEPTH];
+#pragma unroll
+        for (int j = 0; j < ATTN_DEPTH; ++j) sc[j] = 0.f;
         for (int dq = lane; dq < AQ; dq += 64) {
+            float4 k[ATTN_DEPTH];
+#pragma unroll
+            for (int j = 0; j < ATTN_DEPTH; ++j) {
+                const int t = tb + ATTN_WAVES * j;
+                k[j] = t < a.T_in ? kb[(size_t)t * AQ + dq] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             const float4 q = q4[(size_t)dq * a.Bpad + b];
             const float4 vv = v4[dq];
-            const float4 k0 = kb[(size_t)t0 * AQ + dq];
-            s0 += vv.x * dtanh(k0.x + q.x) + vv.y * dtanh(k0.y + q.y) + vv.z * dtanh(k0.z + q.z) +
-                  vv.w * dtanh(k0.w + q.w);
-            if (t1 < a.T_in) {
-                const float4 k1 = kb[(size_t)t1 * AQ + dq];
-                s1 += vv.x * dtanh(k1.x + q.x) + vv.y * dtanh(k1.y + q.y) + vv.z * dtanh(k1.z + q.z) +
-                      vv.w * dtanh(k1.w + q.w);
-            }
+#pragma unroll
+            for (int j = 0; j < ATTN_DEPTH; ++j)
+                sc[j] += vv.x * dtanh(k[j].x + q.x) + vv.y * dtanh(k[j].y + q.y) + vv.z * dtanh(k[j].z + q.z) +
+                         vv.w * dtanh(k[j].w + q.w);
         }
-        s0 = wave_sum(s0);
-        s1 = wave_sum(s1);
-        if (lane == 0) {
-            e[t0] = s0;
-            if (t1 < a.T_in) e[t1] = s1;
+#pragma unroll
+        for (int j = 0; j < ATTN_DEPTH; ++j) {
+            const float s = wave_sum(sc[j]);
+            const int t = tb + ATTN_WAVES * j;
+            if (lane == 0 && t < a.T_in) e[t] = s;
         }
     }
     __syncthreads();
-    // ---- softmax over T_in (max-subtracted, as tf.nn.softmax)
-    float mx = -INFINITY;
-    for (int t = tid; t < a.T_in; t += ATTN_THREADS) mx = fmaxf(mx, e[t]);
-    mx = wave_max(mx);
-    if (lane == 0) redw[wave] = mx;
-    __syncthreads();
-    mx = redw[0];
-#pragma unroll
-    for (int w = 1; w < ATTN_WAVES; ++w) mx = fmaxf(mx, redw[w]);
-    __syncthreads();
-    float sum = 0.f;
-    for (int t = tid; t < a.T_in; t += ATTN_THREADS) {
-        const float p = expf(e[t] - mx);
-        e[t] = p;
-        sum += p;
-    }
-    sum = wave_sum(sum);
-    if (lane == 0) redw[wave] = sum;
-    __syncthreads();
-    sum = redw[0];
-#pragma unroll
-    for (int w = 1; w < ATTN_WAVES; ++w) sum += redw[w];
-    const float inv = 1.f / sum;
-    float* arow = a.align + (size_t)b * a.T_in;
-    for (int t = tid; t < a.T_in; t += ATTN_THREADS) {
-        const float p = e[t] * inv;
-        e[t] = p;
-        arow[t] = p;
+    // ---- softmax over T_in (max-subtracted, as tf.nn.softmax), by wave 0 alone: no block barriers
+    if (wave == 0) {
+        float mx = -INFINITY;
+        for (int t = lane; t < a.T_in; t += 64) mx = fmaxf(mx, e[t]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int t = lane; t < a.T_in; t += 64) {
+            const float p = expf(e[t] - mx);
+            e[t] = p;
+            sum += p;
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        float* arow = a.align + (size_t)b * a.T_in;
+        for (int t = lane; t < a.T_in; t += 64) {
+            const float p = e[t] * inv;
+            e[t] = p;
+            arow[t] = p;
+        }
     }
     __syncthreads();
-    // ---- context
+    // ---- context: wave owns t = wave + 16*j, partial sums reduced across waves in fixed order
     const float4* vb = reinterpret_cast<const float4*>(a.values) + (size_t)b * a.T_in * VQ;
     for (int dq = lane; dq < VQ; dq += 64) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int t = wave; t < a.T_in; t += ATTN_WAVES) {
-            const float4 x = vb[(size_t)t * VQ + dq];
-            const float p = e[t];
-            acc.x = fmaf(p, x.x, acc.x); acc.y = fmaf(p, x.y, acc.y);
-            acc.z = fmaf(p, x.z, acc.z); acc.w = fmaf(p, x.w, acc.w);
+        for (int tb = wave; tb < a.T_in; tb += ATTN_WAVES * ATTN_DEPTH) {
+            float4 x[ATTN_DEPTH];
+#pragma unroll
+            for (int j = 0; j < ATTN_DEPTH; ++j) {
+                const int t = tb + ATTN_WAVES * j;
+                x[j] = t < a.T_in ? vb[(size_t)t * VQ + dq] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < ATTN_DEPTH; ++j) {
+                const int t = tb + ATTN_WAVES * j;
+                const float p = t < a.T_in ? e[t] : 0.f;
+                acc.x = fmaf(p, x[j].x, acc.x); acc.y = fmaf(p, x[j].y, acc.y);
+                acc.z = fmaf(p, x[j].z, acc.z); acc.w = fmaf(p, x[j].w, acc.w);
+            }
         }
         cred[wave * VQ + dq] = acc;
     }
@@ -228,7 +246,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void dec_attention_kernel(DecAttnArgs
 
 void launch_dec_attention(const DecAttnArgs& a, hipStream_t s, Timing* tm) {
     if (tm) tm->begin(KK_DEC_ATTN, s);
-    const size_t shm = (size_t)(((a.T_in + 3) & ~3) + 16) * 4 + (size_t)ATTN_WAVES * (a.Dv / 4) * 16;
+    const size_t shm = (size_t)((a.T_in + 3) & ~3) * 4 + (size_t)ATTN_WAVES * (a.Dv / 4) * 16;
     hipLaunchKernelGGL(dec_attention_kernel, dim3(a.B), dim3(ATTN_THREADS), shm, s, a);
     if (tm) tm->end(KK_DEC_ATTN, s);
 }
@@ -236,22 +254,23 @@ void launch_dec_attention(const DecAttnArgs& a, hipStream_t s, Timing* tm) {
 // ---------------------------------------------------------------------------------------
 // Finalisation: stop test bookkeeping, [S][NR/4][Bpad][4] -> mel [B][S*NR],
 // alignS [S][B][T_in] -> align [B][T_in][S] (model/tacotron.py:51).
-__global__ void dec_steps_kernel(const int32_t* __restrict__ nz, int S, int B, int Bpad, int32_t* steps_run) {
-    // dynamic_decode: finished_b |= all(out_b == 0); stop after the step where all are finished.
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int steps = S;
-    // fin is sticky per utterance; count how many are finished so far
-    // (B is small: a serial scan costs S*B loads once per decode)
-    int nfin = 0;
-    extern __shared__ int32_t fin[];
-    for (int b = 0; b < B; ++b) fin[b] = 0;
-    for (int s = 0; s < S; ++s) {
-        for (int b = 0; b < B; ++b) {
-            if (!fin[b] && nz[(size_t)s * Bpad + b] == 0) { fin[b] = 1; ++nfin; }
-        }
-        if (nfin == B) { steps = s + 1; break; }
+__global__ __launch_bounds__(1024) void dec_steps_kernel(const int32_t* __restrict__ nz, int S, int B, int Bpad,
+                                                         int32_t* steps_run) {
+    // dynamic_decode: finished_b |= all(out_b == 0) (sticky); the loop stops after the first step at which every
+    // utterance is finished. first_zero[b] = first step with an all-zero output; steps = max_b first_zero + 1.
+    extern __shared__ int32_t first_zero[];
+    for (int b = threadIdx.x; b < B; b += blockDim.x) first_zero[b] = S;
+    __syncthreads();
+    for (int i = threadIdx.x; i < S * Bpad; i += blockDim.x) {
+        const int s = i / Bpad, b = i - s * Bpad;
+        if (b < B && nz[i] == 0) atomicMin(&first_zero[b], s);
     }
-    *steps_run = steps;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int steps = 0;
+        for (int b = 0; b < B; ++b) steps = max(steps, first_zero[b] + 1);
+        *steps_run = min(steps, S);
+    }
 }
 
 __global__ void dec_mel_kernel(const float* __restrict__ outQ, const int32_t* __restrict__ steps_run, int S, int NR,
@@ -285,7 +304,7 @@ __global__ void dec_align_kernel(const float* __restrict__ alignS, const int32_t
 void launch_dec_finalize(const float* outQ, const float* alignS, const int32_t* nz, int S, int NR, int B, int Bpad,
                          int T_in, float* mel, float* align, int32_t* steps_run, hipStream_t s, Timing* tm) {
     if (tm) tm->begin(KK_DEC_MISC, s);
-    hipLaunchKernelGGL(dec_steps_kernel, dim3(1), dim3(64), (size_t)B * 4, s, nz, S, B, Bpad, steps_run);
+    hipLaunchKernelGGL(dec_steps_kernel, dim3(1), dim3(1024), (size_t)B * 4, s, nz, S, B, Bpad, steps_run);
     long total = (long)B * S * NR;
     int blocks = (int)std::min<long>(2048, (total + 255) / 256);
     hipLaunchKernelGGL(dec_mel_kernel, dim3(blocks), dim3(256), 0, s, outQ, steps_run, S, NR, B, Bpad, mel);

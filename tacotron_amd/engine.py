@@ -165,7 +165,7 @@ class TacoEngine:
         T = S * r
         _, hop, win = self.hp.stft_params()
         ws = self._workspace(B, T_in, S)
-        o = out or {}
+        o = out if out is not None else {}
         def buf(name, shape, dtype=torch.float32):
             t = o.get(name)
             if t is None or tuple(t.shape) != tuple(shape):

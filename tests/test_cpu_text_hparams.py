@@ -1,0 +1,114 @@
+"""Host logic that runs without a GPU: text frontend against the reference-generated goldens,
+hparams, weight specs, sharding, host DSP."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_text_matches_reference_goldens():
+    """tests/golden/text_goldens.json was produced by importing /root/reference/text
+    (tests/golden/make_text_goldens.py); this is the pinned part of the parity story."""
+    from tacotron_amd.text.characters import chars, pad, eos
+    from tacotron_amd.text.text_tools import text_to_onehot, onehot_to_text
+    g = json.load(open(os.path.join(HERE, 'golden', 'text_goldens.json'), encoding='utf-8'))
+    assert chars == g['chars'] and pad == g['pad'] and eos == g['eos'] and len(chars) == 95
+    for c in g['cases']:
+        ids = [int(i) for i in text_to_onehot(c['text'], 'basic_cleaners')]
+        assert ids == c['ids'], c['text']
+        assert ids[-1] == 1
+        assert onehot_to_text(ids) == c['roundtrip']
+    # the vector recorded in SURVEY.md 8(c)
+    want = [35, 32, 39, 39, 42, 58, 64, 50, 42, 45, 39, 31, 54, 64, 82, 32, 47, 47, 28, 64, 32, 45, 64, 43, 45, 79,
+            33, 64, 86, 87, 88, 64, 1]
+    assert [int(i) for i in text_to_onehot("Hello,  World! Þetta er próf 123 #")] == want
+
+
+def test_hparams_defaults_and_parse():
+    from tacotron_amd.hparams import HParams
+    hp = HParams()
+    assert hp.get('max_iters') == 200 and hp.outputs_per_step == 5 and hp.num_freq == 1025
+    assert hp.stft_params() == (2048, 300, 1200)          # audio.py:161-163
+    hp.parse('max_iters=400,prenet_depths=[256,128],power=1.2')
+    assert hp.max_iters == 400 and hp.prenet_depths == [256, 128] and hp.power == 1.2
+    with pytest.raises(ValueError):
+        hp.parse('no_such_param=1')
+    with pytest.raises(ValueError):
+        hp.parse('max_iters=1.5')
+    assert HParams().max_iters == 200                     # instances do not share state
+
+
+def test_weight_specs_and_initialisers():
+    from tacotron_amd.hparams import HParams
+    from tacotron_amd.weights import init_weights, variable_specs, check_weights, num_params, save_npz, load_npz
+    hp = HParams()
+    specs = variable_specs(hp)
+    names = [n for n, _, _ in specs]
+    assert len(names) == len(set(names))
+    w = init_weights(hp, seed=1)
+    check_weights(w, hp)
+    dec = sum(v.size for k, v in w.items() if k.startswith('decoder/'))
+    assert dec == 1502736                                  # W_step / 4
+    assert w['embedding'].shape == (95, 256) and np.abs(w['embedding']).max() <= 1.0 + 1e-6
+    g = 'encoder_cbhg/bidirectional_rnn/fw/gru_cell/gates/'
+    assert np.all(w[g + 'bias'] == 1.0) and w[g + 'kernel'].shape == (256, 256)
+    assert np.all(w['encoder_cbhg/highway_1/T/bias'] == -1.0)
+    k = w['encoder_cbhg/conv_bank/conv_bank_16/conv1d/kernel']
+    assert k.shape == (16, 128, 128) and np.abs(k).max() <= np.sqrt(6.0 / (16 * 128 * 2))
+    assert 6.8e6 < num_params(w) < 7.1e6
+    bad = dict(w)
+    bad.pop('dense/bias')
+    with pytest.raises(ValueError):
+        check_weights(bad, hp)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, 'model.ckpt-7.npz')
+        save_npz(p, w)
+        w2 = load_npz(p)
+    assert set(w2) == set(w) and all(np.array_equal(w[k], w2[k]) for k in w)
+
+
+def test_shard_helpers():
+    from tacotron_amd.shard import shard_bounds, shard_by_length, gather_order
+    assert shard_bounds(256, 8) == [(32 * i, 32 * i + 32) for i in range(8)]
+    assert shard_bounds(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    lens = np.random.default_rng(0).integers(5, 150, size=37)
+    shards = shard_by_length(lens, 4)
+    cat = np.concatenate(shards)
+    assert sorted(cat.tolist()) == list(range(37))
+    assert all(lens[s].max() >= lens[t].max() for s, t in zip(shards, shards[1:]))
+    inv = gather_order(shards)
+    assert np.array_equal(cat[inv], np.arange(37))
+
+
+def test_host_dsp():
+    from oracle import taco_oracle as O
+    from tacotron_amd.tools import audio
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(5000)
+    assert np.allclose(audio.pre_emphasis_inv(x), O.pre_emphasis_inv(x), rtol=0, atol=1e-9)
+    wav = np.concatenate([0.5 * np.sin(np.arange(30000) / 10.0), np.zeros(40000)])
+    e = audio.find_endpoint(wav)
+    assert e == O.find_endpoint(wav) and 30000 <= e < 40000
+    assert audio.find_endpoint(np.ones(50000)) == 50000
+    import tempfile, wave
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, 'a.wav')
+        audio.save_wav(wav[:1000].copy(), p)
+        with wave.open(p) as f:
+            assert f.getframerate() == 24000 and f.getsampwidth() == 2 and f.getnframes() == 1000
+            pcm = np.frombuffer(f.readframes(1000), '<i2')
+    assert np.array_equal(pcm, O.wav_to_int16(wav[:1000]))
+
+
+def test_batch_and_pad():
+    from tacotron_amd.data.batch import Batch, pad_inputs
+    ids, lens = pad_inputs([[5, 6, 1], [7, 1]])
+    assert ids.tolist() == [[5, 6, 1], [7, 1, 0]] and lens.tolist() == [3, 2]
+    b = Batch((ids, lens, None, None), prep=False)
+    assert b.get_size() == 2 and b.get_all()[2] is None and b.get_input_lengths() is lens
+    with pytest.raises(NotImplementedError):
+        Batch([], prep=True)

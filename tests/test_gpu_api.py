@@ -1,0 +1,175 @@
+"""GPU tests of the host-side API mirror (Tacotron.initialize, Synthesizer, tools.audio) and of
+the BASELINE.json configurations at full size (parity where the oracle finishes in seconds,
+size-independent properties otherwise)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import taco_oracle as O
+from tests.util import rel_l1, synth_ids
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def test_tacotron_initialize_api(hp, weights):
+    from tacotron_amd.data.batch import Batch
+    from tacotron_amd.model.tacotron import Tacotron
+    from tacotron_amd.hparams import HParams
+    hp2 = HParams(max_iters=6)
+    ids, lens = synth_ids(np.random.default_rng(1), 2, 9)
+    m = Tacotron(hp2, weights=weights)
+    m.initialize(Batch((ids, lens, None, None), prep=False))
+    ref = O.tacotron_forward(ids, lens, weights, hp2)
+    assert m.inputs is ids and m.input_lengths is lens and m.mel_targets is None
+    assert tuple(m.mel_outputs.shape) == (2, 30, 80) and tuple(m.linear_outputs.shape) == (2, 30, 1025)
+    assert tuple(m.alignments.shape) == (2, 9, 6)
+    assert rel_l1(_np(m.mel_outputs), ref['mel']) < 1e-3 and rel_l1(_np(m.linear_outputs), ref['linear']) < 1e-3
+    m2 = Tacotron(hp2, weights=weights).initialize(ids, lens)      # convenience form
+    assert np.array_equal(_np(m2.mel_outputs), _np(m.mel_outputs))
+    with pytest.raises(ValueError):
+        m.initialize(np.full((1, 4), 95, np.int32), np.array([4], np.int32))
+    with pytest.raises(ValueError):
+        m.initialize(ids, np.array([9, 10], np.int32))
+    m.engine.close(); m2.engine.close()
+
+
+def test_synthesizer_writes_reference_layout(tmp_path, monkeypatch):
+    import wave
+    from tacotron_amd import synthesizer as S
+    from tacotron_amd.hparams import hparams
+    old = hparams.max_iters, hparams.griffin_lim_iters
+    hparams.max_iters, hparams.griffin_lim_iters = 8, 3
+    try:
+        s = S.Synthesizer().load_random(seed=3)
+        d = str(tmp_path / 'synthesized')
+        os.makedirs(d)
+        s.synthesize('Halló heimur, this is a test.', d)
+        s.synthesize('second sentence', d)
+        lines = open(os.path.join(d, 'index.txt')).read().splitlines()
+        assert len(lines) == 2 and lines[1].endswith('|second sentence')
+        assert lines[0].split('|')[:2] == [os.path.join(d, 'text', 'text-001.txt'), os.path.join(d, 'wavs', 'synth-001.wav')]
+        assert open(os.path.join(d, 'text', 'text-002.txt')).read() == 'second sentence'
+        with wave.open(os.path.join(d, 'wavs', 'synth-001.wav')) as f:
+            assert f.getframerate() == 24000 and f.getnframes() > 0
+        with pytest.raises(FileNotFoundError):
+            S.Synthesizer().load(str(tmp_path / 'model.ckpt'), 5)
+        s.model.engine.close()
+    finally:
+        hparams.max_iters, hparams.griffin_lim_iters = old
+
+
+def test_checkpoint_roundtrip_through_synthesizer(tmp_path, hp, weights):
+    from tacotron_amd import synthesizer as S
+    from tacotron_amd.hparams import hparams
+    from tacotron_amd.weights import save_npz
+    save_npz(str(tmp_path / 'model.ckpt-12.npz'), weights)
+    old = hparams.max_iters
+    hparams.max_iters = 3
+    try:
+        s = S.Synthesizer().load(str(tmp_path / 'model.ckpt'), 12)
+        ids, lens = synth_ids(np.random.default_rng(2), 1, 6)
+        s.model.initialize(ids, lens)
+        ref = O.tacotron_forward(ids, lens, weights, hp, max_iters=3)
+        assert rel_l1(_np(s.model.linear_outputs), ref['linear']) < 1e-3
+        s.model.engine.close()
+    finally:
+        hparams.max_iters = old
+
+
+def test_full_length_parity_cfg1(engine, hp, weights):
+    """BASELINE configs[0] shape (T_in=150, 200 decoder steps -> 1000 frames) against the fp64 oracle after all 200
+    feedback steps: mel/linear within 1e-3 relative L1; attention argmax identical wherever the oracle's margin
+    is above fp32 resolution."""
+    ids, lens = synth_ids(np.random.default_rng(0), 2, 150, ragged=False)
+    ref = O.tacotron_forward(ids, lens, weights, hp)
+    o = engine.finish(engine.synthesize(ids, lens))
+    assert o['steps_run'] == 200
+    e_mel, e_lin = rel_l1(_np(o['mel']), ref['mel']), rel_l1(_np(o['linear']), ref['linear'])
+    al, al_r = _np(o['alignments']), ref['alignments']
+    top = np.sort(al_r, axis=1)
+    decided = (top[:, -1] - top[:, -2]) > 1e-6
+    same = al.argmax(1) == al_r.argmax(1)
+    print('cfg1: mel %.2e linear %.2e argmax same %d/%d decided %d' % (e_mel, e_lin, same.sum(), same.size, decided.sum()))
+    assert e_mel < 1e-3 and e_lin < 1e-3
+    assert np.all(same[decided])
+
+
+def test_ragged_batch_padding_semantics(engine, hp, weights):
+    """A.6/A.8: pad id 0 embeds to a learned row, only the encoder BiGRU masks, attention runs over padded steps."""
+    ids, lens = synth_ids(np.random.default_rng(9), 4, 60, ragged=True, min_len=20)
+    ref = O.tacotron_forward(ids, lens, weights, hp, max_iters=12)
+    o = engine.finish(engine.synthesize(ids, lens, max_iters=12))
+    for k in ('enc_out', 'mel', 'linear', 'alignments'):
+        assert rel_l1(_np(o[k]), ref[k]) < 1e-3, k
+    # padded encoder steps still receive attention mass (no masking in the reference graph)
+    b = int(np.argmin(lens))
+    assert _np(o['alignments'])[b, lens[b]:, :].sum() > 0
+
+
+def test_cfg2_full_size_properties(engine, hp):
+    """configs[1] (B=32, T_in=150, 200 steps): oracle-free properties at full size."""
+    import torch
+    ids, lens = synth_ids(np.random.default_rng(0), 32, 150, ragged=False)
+    o = engine.synthesize(ids, lens)
+    torch.cuda.synchronize()
+    assert int(o['steps'].item()) == 200
+    mel, lin, al = o['mel'], o['linear'], o['alignments']
+    assert tuple(mel.shape) == (32, 1000, 80) and tuple(lin.shape) == (32, 1000, 1025) and tuple(al.shape) == (32, 150, 200)
+    assert bool(torch.isfinite(mel).all()) and bool(torch.isfinite(lin).all())
+    assert torch.allclose(al.sum(1), torch.ones_like(al.sum(1)), atol=1e-5)
+    # shard invariance: any sub-batch gives bit-identical per-utterance results
+    mel_c, lin_c = mel.clone(), lin.clone()
+    o2 = engine.synthesize(ids[8:12], lens[8:12])
+    assert torch.equal(o2['mel'], mel_c[8:12]) and torch.equal(o2['linear'], lin_c[8:12])
+    # determinism: same call twice, bit-identical
+    o3 = engine.synthesize(ids[8:12], lens[8:12])
+    assert torch.equal(o3['linear'], lin_c[8:12])
+
+
+def test_cfg4_long_form(engine, hp, weights):
+    """configs[3]: Ivona long-form, max_iters=400 (2000 frames), 400-character encoder memory."""
+    ids, lens = synth_ids(np.random.default_rng(4), 1, 400, ragged=False)
+    ref = O.tacotron_forward(ids, lens, weights, hp, max_iters=400)
+    o = engine.finish(engine.synthesize(ids, lens, max_iters=400))
+    assert o['steps_run'] == 400 and tuple(o['mel'].shape) == (1, 2000, 80)
+    assert rel_l1(_np(o['mel']), ref['mel']) < 1e-3 and rel_l1(_np(o['linear']), ref['linear']) < 1e-3
+
+
+def test_cfg5_icelandic_text(hp, weights):
+    """configs[4]: Icelandic charset through the same 95-symbol table (ids 75-84 present), B=1."""
+    from tacotron_amd.model.tacotron import Tacotron
+    from tacotron_amd.hparams import HParams
+    from tacotron_amd.text.text_tools import text_to_onehot
+    ids = np.asarray(text_to_onehot('Það er gott veður í dag, þökk sé æðri máttarvöldum.'), np.int32)[None]
+    assert ((ids >= 75) & (ids <= 84)).any()
+    lens = np.array([ids.shape[1]], np.int32)
+    hp2 = HParams(max_iters=20)
+    m = Tacotron(hp2, weights=weights).initialize(ids, lens)
+    ref = O.tacotron_forward(ids, lens, weights, hp2)
+    assert rel_l1(_np(m.mel_outputs), ref['mel']) < 1e-3 and rel_l1(_np(m.linear_outputs), ref['linear']) < 1e-3
+    m.engine.close()
+
+
+def test_griffin_lim_full_length(engine, hp):
+    """One utterance at the default length (T=1000 frames -> 300 900 samples), all 60 iterations."""
+    rng = np.random.default_rng(11)
+    t = np.linspace(0, 1, 1000)[:, None]
+    f = np.linspace(0, 1, 1025)[None, :]
+    lin = np.clip(0.55 + 0.35 * np.sin(40 * t + 9 * f) * np.exp(-2 * f) + 0.05 * rng.standard_normal((1000, 1025)), 0, 1)
+    lin = lin.astype(np.float32)
+    ref = O.spectrogram_tensorflow_inv(lin.astype(np.float64), hp)
+    got = _np(engine.griffin_lim(lin))
+    assert got.shape == ref.shape == (300900,)
+    err = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    print('GL full length: relL2 %.2e' % err)
+    assert err < 1e-3
+    # audio tools wrapper + host post-processing run end to end
+    from tacotron_amd.tools import audio
+    wav = audio.pre_emphasis_inv(_np(audio.inv_spectrogram(lin, engine)))
+    assert wav.shape == (300900,) and np.isfinite(wav).all()
+    assert 0 < audio.find_endpoint(wav) <= len(wav)
