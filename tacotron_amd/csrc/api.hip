@@ -90,6 +90,8 @@ struct taco_ctx {
     TacoHParams hp;
     int device = 0;
     std::vector<void*> allocs;
+    char* arena = nullptr;         // all re-packed weights
+    size_t arena_bytes = 0, arena_off = 0;
     float* enc_lut = nullptr;      // prenet(embedding) [num_chars, prenet2]
     CbhgW enc, post;
     ConvW mem_layer, lin_dense;
@@ -127,13 +129,16 @@ struct Loader {
         }
         return e;
     }
+    // All device-side weights live in ONE allocation (sub-allocated at 256 B granularity): a decoder step touches
+    // ~25 weight/bias arrays per step, and separate hipMallocs would put each on its own page-table fragment.
     float* upload(const std::vector<float>& h) {
-        void* d = nullptr;
-        if (hipMalloc(&d, std::max<size_t>(h.size(), 4) * sizeof(float)) != hipSuccess) {
-            if (err.empty()) err = "hipMalloc failed for weights";
+        const size_t bytes = (std::max<size_t>(h.size(), 4) * sizeof(float) + 255) & ~(size_t)255;
+        if (c->arena_off + bytes > c->arena_bytes) {
+            if (err.empty()) err = "weight arena overflow";
             return nullptr;
         }
-        c->allocs.push_back(d);
+        char* d = c->arena + c->arena_off;
+        c->arena_off += bytes;
         if (hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
             if (err.empty()) err = "hipMemcpy failed for weights";
             return nullptr;
@@ -443,8 +448,26 @@ extern "C" int taco_create(const TacoHParams* hp, const TacoWeightEntry* weights
     c->device = device;
     Loader L;
     L.c = c;
-    for (int i = 0; i < n_weights; ++i)
-        if (weights[i].name) L.tab[weights[i].name] = &weights[i];
+    size_t total = 0;
+    for (int i = 0; i < n_weights; ++i) {
+        if (!weights[i].name) continue;
+        L.tab[weights[i].name] = &weights[i];
+        size_t n = 1;
+        for (int d = 0; d < weights[i].ndim && d < 4; ++d) n *= (size_t)std::max<int64_t>(weights[i].dims[d], 1);
+        total += n;
+    }
+    // packed copies pad N to 128 columns (num_freq 1025 -> 1152) and add folded BN / tables: 2x + 16 MB is ample
+    c->arena_bytes = total * sizeof(float) * 2 + (16u << 20);
+    {
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, c->arena_bytes);
+        if (e != hipSuccess) {
+            delete c;
+            return fail("taco_create: hipMalloc(%zu) failed: %s", c->arena_bytes, hipGetErrorString(e));
+        }
+        c->arena = (char*)d;
+        c->allocs.push_back(d);
+    }
 
     const int G2 = 2 * p.encoder_gru_cells;   // encoder output depth
     const int NR = p.num_mels * p.outputs_per_step;

@@ -27,6 +27,13 @@ __device__ __forceinline__ float dtanh(float x) {
     return 1.f - 2.f / (e + 1.f);
 }
 
+// tanh for the attention scores (T_in*256 evaluations per utterance-step): hardware exp2 + rcp,
+// 1 - 2/(2^(2x log2 e) + 1); absolute error ~2e-7, saturates cleanly. The GRU epilogues keep expf.
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+}
+
 constexpr int DG_WAVES = 8;       // K is split over 8 waves (fixed chunks => fixed summation order)
 constexpr int DG_THREADS = 64 * DG_WAVES;
 constexpr int DG_DEPTH = 4;       // k16-steps whose loads are issued together per wave
@@ -47,6 +54,20 @@ __global__ __launch_bounds__(DG_THREADS) void dec_gemm_kernel(DecGemmArgs a) {
     const float4* s1 = reinterpret_cast<const float4*>(a.src1);
     const int lb = b0 + (lane & 15);
     const int lq = lane >> 4;
+    // epilogue operands of wave 0 are requested up front so their latency hides under the K loop
+    const int n = ntile * 16 + 4 * lq;                 // first of this lane's 4 output rows
+    const size_t e = (size_t)(n >> 2) * a.Bpad + lb;   // float4 index in a Q-layout buffer of dimension N
+    f32x4 pbias = {0.f, 0.f, 0.f, 0.f}, ph = pbias, pu = pbias, pres = pbias;
+    if (wave == 0) {
+        if (a.bias) pbias = *reinterpret_cast<const f32x4*>(a.bias + n);
+        if (a.epi == DE_GATES) {
+            if (n < (a.N >> 1)) ph = reinterpret_cast<const f32x4*>(a.h)[e];
+        } else if (a.epi == DE_CAND) {
+            ph = reinterpret_cast<const f32x4*>(a.h)[e];
+            pu = reinterpret_cast<const f32x4*>(a.u)[e];
+            if (a.res_out) pres = reinterpret_cast<const f32x4*>(a.res)[e];
+        }
+    }
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     for (int base = ks_begin; base < ks_end; base += DG_DEPTH) {
         float4 w[DG_DEPTH], x[DG_DEPTH];
@@ -78,12 +99,7 @@ __global__ __launch_bounds__(DG_THREADS) void dec_gemm_kernel(DecGemmArgs a) {
 #pragma unroll
     for (int w = 1; w < DG_WAVES; ++w) v += red[w][lane];
 
-    const int n = ntile * 16 + 4 * lq;                 // first of this lane's 4 output rows
-    const size_t e = (size_t)(n >> 2) * a.Bpad + lb;   // float4 index in a Q-layout buffer of dimension N
-    if (a.bias) {
-        const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
-        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-    }
+    v += pbias;
     switch (a.epi) {
         case DE_LINEAR:
             reinterpret_cast<f32x4*>(a.out)[e] = v;
@@ -102,8 +118,7 @@ __global__ __launch_bounds__(DG_THREADS) void dec_gemm_kernel(DecGemmArgs a) {
             g.x = dsigmoid(v.x); g.y = dsigmoid(v.y); g.z = dsigmoid(v.z); g.w = dsigmoid(v.w);
             const int H = a.N >> 1;
             if (n < H) {
-                const f32x4 hv = reinterpret_cast<const f32x4*>(a.h)[e];
-                reinterpret_cast<f32x4*>(a.out)[e] = g * hv;                         // r * h
+                reinterpret_cast<f32x4*>(a.out)[e] = g * ph;                         // r * h
             } else {
                 reinterpret_cast<f32x4*>(a.u)[e - (size_t)(H >> 2) * a.Bpad] = g;   // u
             }
@@ -112,11 +127,9 @@ __global__ __launch_bounds__(DG_THREADS) void dec_gemm_kernel(DecGemmArgs a) {
         case DE_CAND: {
             f32x4 c;
             c.x = dtanh(v.x); c.y = dtanh(v.y); c.z = dtanh(v.z); c.w = dtanh(v.w);
-            const f32x4 u = reinterpret_cast<const f32x4*>(a.u)[e];
-            const f32x4 hv = reinterpret_cast<const f32x4*>(a.h)[e];
-            const f32x4 hn = u * hv + (1.f - u) * c;
+            const f32x4 hn = pu * ph + (1.f - pu) * c;
             reinterpret_cast<f32x4*>(a.h)[e] = hn;
-            if (a.res_out) reinterpret_cast<f32x4*>(a.res_out)[e] = hn + reinterpret_cast<const f32x4*>(a.res)[e];
+            if (a.res_out) reinterpret_cast<f32x4*>(a.res_out)[e] = hn + pres;
             break;
         }
         case DE_OUT: {
@@ -182,8 +195,8 @@ __global__ __launch_bounds__(ATTN_THREADS) void dec_attention_kernel(DecAttnArgs
             const float4 vv = v4[dq];
 #pragma unroll
             for (int j = 0; j < ATTN_DEPTH; ++j)
-                sc[j] += vv.x * dtanh(k[j].x + q.x) + vv.y * dtanh(k[j].y + q.y) + vv.z * dtanh(k[j].z + q.z) +
-                         vv.w * dtanh(k[j].w + q.w);
+                sc[j] += vv.x * fast_tanh(k[j].x + q.x) + vv.y * fast_tanh(k[j].y + q.y) +
+                         vv.z * fast_tanh(k[j].z + q.z) + vv.w * fast_tanh(k[j].w + q.w);
         }
 #pragma unroll
         for (int j = 0; j < ATTN_DEPTH; ++j) {
