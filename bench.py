@@ -129,6 +129,8 @@ def main():
     ap.add_argument('--t-in', type=int, default=150)
     ap.add_argument('--max-iters', type=int, default=200)
     ap.add_argument('--to-wav', action='store_true', help='include the 60-iteration Griffin-Lim (configs[2])')
+    ap.add_argument('--streams', type=int, default=1,
+                    help='independent batches in flight per GPU: step i runs on engine/stream i %% streams')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -149,16 +151,24 @@ def main():
     hp = HParams()
     hp.max_iters = args.max_iters
     weights = init_weights(hp, seed=1234)          # "random-init weights" (BASELINE.json configs)
-    eng = TacoEngine(weights, hp, device=local)
+    engines = [TacoEngine(weights, hp, device=local) for _ in range(max(1, args.streams))]
+    eng = engines[0]
+    torch.cuda.synchronize()
+    for e in engines:
+        e.detached = True          # independent streams; the timed region synchronises the device at both ends
     B, T_in, S = args.batch, args.t_in, args.max_iters
     # this rank's shard of the synthetic job: utterances [rank*B, (rank+1)*B)
     ids_all, lens_all = synth_ids(np.random.default_rng(0), B * world, T_in, ragged=False)
     ids = torch.from_numpy(ids_all[rank * B:(rank + 1) * B]).to(eng.device)
     lens = torch.from_numpy(lens_all[rank * B:(rank + 1) * B]).to(eng.device)
-    out = {}
+    outs = [{} for _ in engines]
+    out = outs[0]
+    counter = [0]
 
     def step():
-        eng.synthesize(ids, lens, max_iters=S, to_wav=args.to_wav, out=out)
+        i = counter[0] % len(engines)
+        counter[0] += 1
+        engines[i].synthesize(ids, lens, max_iters=S, to_wav=args.to_wav, out=outs[i])
 
     def barrier():
         torch.cuda.synchronize()
@@ -166,8 +176,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, len(engines))):
         step()
+    barrier()
+    # single-batch latency (one batch in flight), for the p50 figure
+    lat = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        eng.synthesize(ids, lens, max_iters=S, to_wav=args.to_wav, out=out)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t0)
+    lat_ms = 1e3 * sorted(lat)[len(lat) // 2]
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -192,8 +211,9 @@ def main():
                                    B, T_in, S, hp.outputs_per_step,
                                    ' + 60-iter Griffin-Lim wav' if args.to_wav else ''),
                    'batch_per_gpu': B, 'global_batch': B * world, 'T_in': T_in, 'max_iters': S,
-                   'frames_per_utterance': steps_run * hp.outputs_per_step, 'parallelism': 'utterance-sharded x%d' % world},
-        'p50_batch_latency_ms': 1e3 * el / args.steps,
+                   'frames_per_utterance': steps_run * hp.outputs_per_step, 'parallelism': 'utterance-sharded x%d' % world,
+                   'streams_per_gpu': len(engines)},
+        'p50_batch_latency_ms': lat_ms, 'batches_in_flight': len(engines),
     }
 
     if rank == 0 and not args.no_roofline:
@@ -223,8 +243,14 @@ def main():
             ach, peak, unit = per_launch / sec / 1e9, HBM_PEAK_GBS, 'GB/s'
         else:
             ach, peak, unit = per_launch / sec / 1e12, FP32_MFMA_PEAK_TF, 'TFLOP/s'
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+            traffic = tj.get('B%d_Tin%d_S%d' % (B, T_in, S), {}).get(dom, {}).get('bytes_per_launch')
+        except Exception:
+            traffic = None
         res['roofline'] = {'kernel': dom, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit,
-                           'frac': ach / peak, 'traffic': None, 'launches_per_step': leaf[dom]['launches'],
+                           'frac': ach / peak, 'traffic': traffic, 'launches_per_step': leaf[dom]['launches'],
                            'avg_launch_us': 1e6 * sec, 'algorithmic_per_launch': per_launch}
         if 'decode_graph' in fam:
             b, amt = work['decode_graph']
@@ -238,7 +264,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    for e in engines:
+        e.close()
 
 
 if __name__ == '__main__':

@@ -74,11 +74,19 @@ class TacoEngine:
         t = torch.as_tensor(np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x)
         return t.to(device=self.device, dtype=dtype).contiguous()
 
+    # By default every call is ordered after torch's current stream and torch's current stream after it, so
+    # callers can mix engine calls with ordinary torch code. `detached = True` drops both edges: the engine's
+    # stream then runs independently (several engines = several batches in flight on one GPU) and the caller
+    # synchronises explicitly (torch.cuda.synchronize / engine.stream.synchronize).
+    detached = False
+
     def _enter(self):
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        if not self.detached:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
 
     def _leave(self):
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        if not self.detached:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
     @property
     def _s(self):
