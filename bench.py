@@ -131,6 +131,7 @@ def main():
     ap.add_argument('--to-wav', action='store_true', help='include the 60-iteration Griffin-Lim (configs[2])')
     ap.add_argument('--streams', type=int, default=1,
                     help='independent batches in flight per GPU: step i runs on engine/stream i %% streams')
+    ap.add_argument('--decode-mode', type=int, default=2, help='0 eager per-stage kernels, 1 hipGraph, 2 persistent kernel')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -155,6 +156,7 @@ def main():
     eng = engines[0]
     torch.cuda.synchronize()
     for e in engines:
+        e.set_decode_graph(args.decode_mode)
         e.detached = True          # independent streams; the timed region synchronises the device at both ends
     B, T_in, S = args.batch, args.t_in, args.max_iters
     # this rank's shard of the synthetic job: utterances [rank*B, (rank+1)*B)

@@ -143,9 +143,14 @@ int taco_timing_end(taco_handle h, int32_t* launches, double* total_ms);
 const char* taco_kernel_name(int32_t kind);
 int32_t taco_num_kernel_kinds(void);
 
-/* Selects how taco_decode issues its per-step kernels: 0 = eager launches,
- * 1 = one captured hipGraph per (B, T_in, max_iters, buffers) replayed (default). */
-int taco_set_decode_graph(taco_handle h, int32_t enable);
+/* Selects how taco_decode runs the loop: 0 = one kernel per stage, eager launches; 1 = the same kernels
+ * captured once per (B, T_in, max_iters, buffers) into a hipGraph and replayed; 2 (default) = one persistent
+ * kernel for the whole loop (default layer sizes, no dropout replay, B <= 128; otherwise mode 1 is used). */
+int taco_set_decode_graph(taco_handle h, int32_t mode);
+
+/* Synchronous check of the last persistent decode (reads a few device words; call after the stream has been
+ * synchronised): <0 if one of its bounded inter-workgroup waits timed out, in which case its outputs are invalid. */
+int taco_decode_status(taco_handle h);
 
 /* Test hook (no reference counterpart): one launch of the dense / SAME-conv1d implicit-GEMM
  * kernel, C[m,n] = (act(sum_{j,c} X[b,t+j-padl,c] W[j*Cin+c,n] + bias[n])) * scale[n] + shift[n]

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -56,7 +57,7 @@ void Timing::end(int k, hipStream_t s) {
 
 static const char* kKernelNames[KK_COUNT] = {
     "conv_gemm", "highway_combine", "embed_gather", "bigru_scan", "dec_gemm", "dec_attention",
-    "dec_finalize", "decode_graph", "gl_mag", "gl_iter", "gl_ola"};
+    "dec_finalize", "decode_graph", "gl_mag", "gl_iter", "gl_ola", "dec_persistent"};
 
 // ---------------------------------------------------------------------------------------
 // weights on the device
@@ -101,7 +102,10 @@ struct taco_ctx {
     float* window = nullptr;
     Timing timing;
     bool timing_on = false;
-    int use_graph = 1;
+    int decode_mode = 2;           // 0 eager per-stage kernels, 1 captured hipGraph of them, 2 persistent kernel
+    unsigned long long* sync_words = nullptr;  // persistent decoder: per 16-utterance group {counter, abort}, 128 B apart
+    int last_sync_groups = 0;                  // groups used by the last decode if it was persistent, else 0
+    unsigned long long* dbg_stamps = nullptr;  // PD_STAMPS builds: 64 s_memrealtime stamps of one step
     std::vector<GraphEntry> graphs;
 };
 
@@ -332,6 +336,7 @@ size_t dec_ws_bytes(const taco_ctx* c, int B, int T_in, int S) {
     n += al((size_t)S * NR * Bp * 4);                                        // outQ
     n += al((size_t)S * B * T_in * 4);                                       // alignS
     n += al((size_t)S * Bp * 4);                                             // nz
+    n += al(((size_t)4816 * Bp * 2 + 4096 + (size_t)B * T_in * 2 + 64 + (size_t)S * 400 * Bp * 2) * 4) + 4096;  // persistent decoder region
     const size_t state = (size_t)(hp.num_mels + Dv + hp.attention_depth + 2 * hp.decoder_depth) * Bp * 4;
     n += al(state);
     const int mx = std::max(hp.attention_depth, hp.decoder_depth);
@@ -512,7 +517,8 @@ extern "C" int taco_create(const TacoHParams* hp, const TacoWeightEntry* weights
         for (int n = 0; n < p.win_length; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / p.win_length));
         c->twiddle = L.upload(tw);
         c->window = L.upload(win);
-        ok = c->twiddle && c->window;
+        c->sync_words = reinterpret_cast<unsigned long long*>(L.upload(std::vector<float>(8 * 32, 0.f)));
+        ok = c->twiddle && c->window && c->sync_words;
     }
     if (ok) {
         // encoder prenet of every symbol, once: prenet(embedding[id]) is a pure function of the id
@@ -659,6 +665,42 @@ static void decode_steps(taco_ctx* c, const DecBufs& d, const float* enc_out, co
     }
 }
 
+// Persistent decode kernels need all their workgroups resident at once (one per CU). Launches from several
+// streams / handles of this process are therefore admitted against the device's CU count: a launch that would
+// not fit waits (on the device, via an event) for the oldest launches still in flight.
+namespace {
+struct PersistSlot { hipEvent_t ev; int wgs; };
+std::mutex g_persist_mu;
+std::map<int, std::vector<PersistSlot>> g_persist_active;   // per device, launch order
+
+int persist_admit(int device, int wgs, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_persist_mu);
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    if (wgs > cus) return -1;
+    auto& v = g_persist_active[device];
+    for (size_t i = 0; i < v.size();) {
+        if (hipEventQuery(v[i].ev) == hipSuccess) { (void)hipEventDestroy(v[i].ev); v.erase(v.begin() + i); }
+        else ++i;
+    }
+    int inflight = 0;
+    for (auto& p : v) inflight += p.wgs;
+    for (size_t i = 0; i < v.size() && inflight + wgs > cus; ++i) {
+        (void)hipStreamWaitEvent(s, v[i].ev, 0);
+        inflight -= v[i].wgs;
+    }
+    return 0;
+}
+void persist_launched(int device, int wgs, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_persist_mu);
+    PersistSlot p;
+    if (hipEventCreateWithFlags(&p.ev, hipEventDisableTiming) != hipSuccess) return;
+    (void)hipEventRecord(p.ev, s);
+    p.wgs = wgs;
+    g_persist_active[device].push_back(p);
+}
+}  // namespace
+
 static int decode_impl(taco_ctx* c, const float* enc_out, int B, int T_in, int S, const float* keep, float* mel,
                        float* align, int32_t* steps_run, Carver& ws, hipStream_t s) {
     const TacoHParams& hp = c->hp;
@@ -668,43 +710,96 @@ static int decode_impl(taco_ctx* c, const float* enc_out, int B, int T_in, int S
     const int Dv = 2 * hp.encoder_gru_cells;
     const int A = hp.attention_depth, D = hp.decoder_depth;
     if (T_in > 8192) return fail("taco_decode: T_in > 8192 not supported by the attention kernel");
+    const int mx = std::max(A, D);
     DecBufs d;
     d.keys = ws.take<float>((size_t)B * T_in * A);
-    d.outQ = ws.take<float>((size_t)S * NR * Bp);
     d.alignS = ws.take<float>((size_t)S * B * T_in);
     d.nz = ws.take<int32_t>((size_t)S * Bp);
+    unsigned long long* sync = c->sync_words;   // handle-owned (not workspace): survives later stages for taco_decode_status
+    c->last_sync_groups = 0;
+    // one contiguous region for everything the decoder-step kernels exchange (Q layout)
     const size_t state_floats = (size_t)(hp.num_mels + Dv + A + 2 * D) * Bp;
-    d.go = ws.take<float>(state_floats);
-    d.ctx = d.go + (size_t)hp.num_mels * Bp;
-    d.hatt = d.ctx + (size_t)Dv * Bp;
-    d.h1 = d.hatt + (size_t)A * Bp;
-    d.h2 = d.h1 + (size_t)D * Bp;
-    d.state_bytes = state_floats * 4;
-    const int mx = std::max(A, D);
-    d.p1 = ws.take<float>((size_t)hp.prenet_depth1 * Bp);
-    d.p2 = ws.take<float>((size_t)hp.prenet_depth2 * Bp);
-    d.rh = ws.take<float>((size_t)mx * Bp);
-    d.u = ws.take<float>((size_t)mx * Bp);
-    d.q = ws.take<float>((size_t)mx * Bp);
-    d.d0 = ws.take<float>((size_t)mx * Bp);
-    d.o1 = ws.take<float>((size_t)mx * Bp);
-    d.o2 = ws.take<float>((size_t)mx * Bp);
+    const size_t e_floats = ((size_t)B * T_in + 63) & ~(size_t)63;
+    const size_t region_floats = state_floats + (size_t)(hp.prenet_depth1 + hp.prenet_depth2 + 6 * mx) * Bp + e_floats +
+                                 (size_t)S * NR * Bp;
+    float* region = ws.take<float>(region_floats);
     if (!ws.ok()) return fail("taco_decode: workspace too small");
+    float* p = region;
+    d.go = p; p += (size_t)hp.num_mels * Bp;
+    d.ctx = p; p += (size_t)Dv * Bp;
+    d.hatt = p; p += (size_t)A * Bp;
+    d.h1 = p; p += (size_t)D * Bp;
+    d.h2 = p; p += (size_t)D * Bp;
+    d.state_bytes = state_floats * 4;
+    d.p1 = p; p += (size_t)hp.prenet_depth1 * Bp;
+    d.p2 = p; p += (size_t)hp.prenet_depth2 * Bp;
+    d.rh = p; p += (size_t)mx * Bp;
+    d.u = p; p += (size_t)mx * Bp;
+    d.q = p; p += (size_t)mx * Bp;
+    d.d0 = p; p += (size_t)mx * Bp;
+    d.o1 = p; p += (size_t)mx * Bp;
+    d.o2 = p; p += (size_t)mx * Bp;
+    p += e_floats;   // (spare)
+    d.outQ = p;
 
-    // whole decode as one enqueue sequence; optionally captured once per shape/buffer set and replayed
-    auto enqueue = [&](Timing* t) {
+    auto keys_gemm = [&](Timing* t) {
         // keys = memory_layer(enc_out), once per utterance (BahdanauAttention ctor, decoder.py:20)
         GemmArgs g{enc_out, Dv, B * T_in, T_in, c->mem_layer.Cin, 1, 0, c->mem_layer.W, c->mem_layer.ldw,
                    c->mem_layer.N, nullptr, nullptr, nullptr, nullptr, 0, d.keys, A, ACT_NONE, 0};
         launch_conv_gemm(g, s, t);
-        (void)hipMemsetAsync(d.go, 0, d.state_bytes, s);                    // zero_state + <GO> frame (decoder.py:36, helpers.py:80-85)
-        (void)hipMemsetAsync(d.nz, 0, (size_t)S * Bp * 4, s);
-        decode_steps(c, d, enc_out, keep, B, T_in, S, s, t);
-        launch_dec_finalize(d.outQ, d.alignS, d.nz, S, NR, B, Bp, T_in, mel, align, steps_run, s, t);
+        (void)hipMemsetAsync(d.go, 0, d.state_bytes, s);   // zero_state + <GO> frame (decoder.py:36, helpers.py:80-85)
     };
+    const bool fine_timing = c->timing_on && (c->timing.kind == KK_DEC_GEMM || c->timing.kind == KK_DEC_ATTN);
 
-    const bool fine_timing = c->timing_on && c->timing.kind != KK_DEC_GRAPH;
-    if (!c->use_graph || s == nullptr || fine_timing) {
+    // ---- mode 2: the whole loop as one persistent launch (default layer sizes, inference: no dropout replay)
+    const bool default_sizes = hp.prenet_depth1 == 256 && hp.prenet_depth2 == 128 && A == 256 && D == 256 &&
+                               hp.num_mels == 80 && hp.outputs_per_step == 5 && Dv == 256;
+    const size_t g1 = (size_t)Bp * 2;                        // floats per unit of vector dimension, granule layout
+    const size_t pe_floats = (((size_t)B * T_in * 2) + 63) & ~(size_t)63;
+    const size_t pregion_floats = (size_t)(80 + 256 + 6 * 256 + 256 + 128 + 3 * 256 + 3 * 256 + 4 * 256) * g1 + pe_floats +
+                                  (size_t)S * 400 * g1;
+    if (c->decode_mode == 2 && default_sizes && !keep && !fine_timing && Bp / 16 <= 8 &&
+        pregion_floats * 4 < (size_t)1 << 31) {
+        float* pregion = ws.take<float>(pregion_floats + 1024);   // + 4 KB tail for diagnostic stamps (PD_STAMPS builds)
+        if (!ws.ok()) return fail("taco_decode: workspace too small");
+        GemmArgs g{enc_out, Dv, B * T_in, T_in, c->mem_layer.Cin, 1, 0, c->mem_layer.W, c->mem_layer.ldw,
+                   c->mem_layer.N, nullptr, nullptr, nullptr, nullptr, 0, d.keys, A, ACT_NONE, 0};
+        launch_conv_gemm(g, s, tm);
+        // every exchanged buffer starts as {0, tag 0}: zero_state, <GO> frame, and no stale tags of an earlier call
+        (void)hipMemsetAsync(pregion, 0, (pregion_floats + 1024) * 4, s);
+        c->dbg_stamps = reinterpret_cast<unsigned long long*>(pregion + pregion_floats);
+        (void)hipMemsetAsync(sync, 0, 128, s);
+        DecPersistArgs a{};
+        const DecW* W[11] = {&c->pre1, &c->pre2, &c->att_g, &c->att_c, &c->query, &c->proj,
+                             &c->g1_g, &c->g1_c, &c->g2_g, &c->g2_c, &c->outp};
+        for (int i = 0; i < 11; ++i) { a.Wp[i] = W[i]->Wp; a.bias[i] = W[i]->bias; }
+        a.attn_v = c->attn_v; a.keys = d.keys; a.values = enc_out;
+        a.region = pregion; a.region_bytes = (unsigned)(pregion_floats * 4);
+        size_t o = 0;
+        auto takeg = [&](int dim) { const unsigned r = (unsigned)o; o += (size_t)dim * g1; return r; };
+        a.o_go = takeg(80); a.o_ctx = takeg(256); a.o_hatt = takeg(512); a.o_h1 = takeg(512); a.o_h2 = takeg(512);
+        a.o_p1 = takeg(256); a.o_p2 = takeg(128); a.o_rh = takeg(768); a.o_u = takeg(768); a.o_q = takeg(256);
+        a.o_d0 = takeg(256); a.o_o1 = takeg(256); a.o_o2 = takeg(256);
+        a.o_e = (unsigned)o; o += pe_floats;
+        a.o_outQ = (unsigned)o;
+        a.alignS = d.alignS; a.sync = sync; a.B = B; a.Bpad = Bp; a.T_in = T_in; a.S = S;
+        a.dbg = c->dbg_stamps;
+        const int wgs = 32 * (Bp / 16);
+        if (persist_admit(c->device, wgs, s)) return fail("taco_decode: persistent decoder does not fit the device");
+        if (launch_dec_persistent(a, s, tm)) return fail("taco_decode: cannot configure the persistent decoder");
+        persist_launched(c->device, wgs, s);
+        c->last_sync_groups = 1;
+        launch_dec_finalize(pregion + a.o_outQ, 1, d.alignS, d.nz, S, NR, B, Bp, T_in, mel, align, steps_run, s, tm);
+        return 0;
+    }
+
+    // ---- modes 0/1: one kernel per stage; eager, or captured once per shape/buffer set and replayed
+    auto enqueue = [&](Timing* t) {
+        keys_gemm(t);
+        decode_steps(c, d, enc_out, keep, B, T_in, S, s, t);
+        launch_dec_finalize(d.outQ, 0, d.alignS, d.nz, S, NR, B, Bp, T_in, mel, align, steps_run, s, t);
+    };
+    if (c->decode_mode == 0 || s == nullptr || (c->timing_on && c->timing.kind != KK_DEC_GRAPH)) {
         enqueue(tm);
         return 0;
     }
@@ -863,9 +958,29 @@ extern "C" int taco_timing_end(taco_handle h, int32_t* launches, double* total_m
 extern "C" const char* taco_kernel_name(int32_t kind) { return kind >= 0 && kind < KK_COUNT ? kKernelNames[kind] : ""; }
 extern "C" int32_t taco_num_kernel_kinds(void) { return KK_COUNT; }
 
-extern "C" int taco_set_decode_graph(taco_handle h, int32_t enable) {
+extern "C" int taco_set_decode_graph(taco_handle h, int32_t mode) {
     if (!h) return fail("taco_set_decode_graph: null handle");
-    h->use_graph = enable ? 1 : 0;
+    if (mode < 0 || mode > 2) return fail("taco_set_decode_graph: mode must be 0, 1 or 2");
+    h->decode_mode = mode;
+    return 0;
+}
+
+extern "C" int taco_decode_status(taco_handle h) {
+    if (!h) return fail("taco_decode_status: null handle");
+    if (!h->last_sync_groups) return 0;
+    HIP_OK(hipSetDevice(h->device));
+    unsigned long long w = 0;
+    HIP_OK(hipMemcpy(&w, h->sync_words, 8, hipMemcpyDeviceToHost));
+#ifdef PD_STAMPS
+    if (h->dbg_stamps) {
+        unsigned long long st[64];
+        HIP_OK(hipMemcpy(st, h->dbg_stamps, sizeof(st), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pd stamps, 10 ns ticks since step start]");
+        for (int i = 1; i < 64 && st[i]; ++i) fprintf(stderr, " %llu", st[i] - st[0]);
+        fprintf(stderr, "\n");
+    }
+#endif
+    if (w >> 32) return fail("persistent decoder: a bounded inter-workgroup wait timed out; outputs are invalid");
     return 0;
 }
 

@@ -1,0 +1,464 @@
+// dec_persistent: the whole dynamic_decode loop (model/decoder.py:18-40, model/rnn_wrappers.py,
+// model/helpers.py:66-78; step maths SURVEY.md A.7) as ONE launch for the default layer sizes
+// (prenet 256/128, attention/decoder depth 256, 80 mels x r=5, 256-wide encoder memory).
+//
+// Why: a decoder step is a chain of 13 dependent all-to-all stages with ~1 us of arithmetic each; as separate
+// kernels every stage pays a dispatch boundary and re-streams its weights.  Here
+//   * each b-tile of 16 utterances is owned by a group of 32 workgroups (one per CU, 512 threads);
+//     workgroup j computes the same 16-row output tile j of every stage for all S steps, so its
+//     slices of ALL decoder weights (~316 KB) stay in registers for the whole decode: per step no weight
+//     byte moves (4 waves, one per SIMD, 70 dwordx4 per lane loaded once; VGPR+AGPR file of 512);
+//   * the GRU state / residual tiles a workgroup owns stay in registers as well;
+//   * the encoder memory of an utterance is staged once into the LDS of the two workgroups that
+//     share its attention (keys: each half of T_in; values: each half of the 256 channels), when it fits
+//     (T_in <= 150 at the default sizes; otherwise it is read from L2);
+//   * stages hand activations over through a small global region in the decoder-step "Q layout"
+//     (decoder.hip) with write-through (sc1) 16-byte stores, every storing wave drains its stores
+//     (s_waitcnt vmcnt(0)), one lane per workgroup arrives on the group's monotonic counter with an
+//     agent-scope atomic add and polls it with sc1 loads; after the workgroup barrier that follows,
+//     every load of handed-off bytes is an sc1 buffer load (bypasses the CU's L1, which other CUs'
+//     stores never refresh).  Placement-independent; no reliance on dispatch order or XCD sharing.
+//   * every spin is bounded: on timeout the group's abort word is set, all waits fall through and
+//     the host reports the error.
+// Reductions have a fixed order of their own (K split over 4 waves, two workgroups per utterance in the
+// attention): results are reproducible and batch-independent, and differ from the per-stage kernels
+// (decoder.hip, K over 8 waves) only by fp32 rounding.
+#include "kernels.h"
+#include "dec_common.h"
+
+namespace taco {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int PD_THREADS = 256;   // one wave per SIMD: each wave may use the whole 512-entry register file
+constexpr int PD_WAVES = 4;
+constexpr unsigned PD_SPIN_LIMIT = 1u << 21;   // polls (>= ~0.5 us each) before a wait gives up
+constexpr int PD_BATCH = 2;                    // k16-steps fetched (and tag-checked) together
+constexpr int PD_STAGES = 13;                  // hand-off points per decoder step
+
+enum { ST_PRE1 = 0, ST_PRE2, ST_ATTG, ST_ATTC, ST_QUERY, ST_PROJ, ST_G1G, ST_G1C, ST_G2G, ST_G2C, ST_OUT, ST_COUNT };
+
+// ---- granule transport ---------------------------------------------------------------------------------
+// Every value a workgroup hands to others travels as an 8-byte {value, tag} granule written by a write-through
+// (sc1) store and read by sc1 loads (L1-bypassing): the data is its own flag, so a hand-off costs one
+// store -> load hop and no separate counter, fence or barrier. tag = 13*step + producing stage + 1 (never 0);
+// buffers are zero-filled before the launch, so initial state carries tag 0. A Q-layout quad {x[k..k+3]} of
+// batch column b is the 32 bytes {x0,tag,x1,tag,x2,tag,x3,tag} at float offset ((k/4)*Bpad + b)*8, moved as two
+// 16-byte accesses whose 8-byte halves are each one granule.
+struct GQuad { u32x4 lo, hi; };
+__device__ __forceinline__ GQuad pd_ldg(__amdgpu_buffer_rsrc_t rs, unsigned float_off) {
+    GQuad g;
+    g.lo = __builtin_amdgcn_raw_buffer_load_b128(rs, float_off * 4u, 0, 16 /* sc1 */);
+    g.hi = __builtin_amdgcn_raw_buffer_load_b128(rs, float_off * 4u + 16u, 0, 16);
+    return g;
+}
+__device__ __forceinline__ bool gq_ok(const GQuad& g, unsigned tag) {
+    return g.lo.y == tag && g.lo.w == tag && g.hi.y == tag && g.hi.w == tag;
+}
+__device__ __forceinline__ f32x4 gq_val(const GQuad& g) {
+    // (element-wise __builtin_bit_cast on ext_vector members miscompiles with this hipcc: use the intrinsics)
+    const unsigned a = g.lo.x, b = g.lo.z, c = g.hi.x, d = g.hi.z;
+    return f32x4{__uint_as_float(a), __uint_as_float(b), __uint_as_float(c), __uint_as_float(d)};
+}
+__device__ __forceinline__ void pd_stg(__amdgpu_buffer_rsrc_t rs, unsigned float_off, f32x4 v, unsigned tag) {
+    const float a = v.x, b = v.y, c = v.z, d = v.w;
+    const u32x4 lo = {__float_as_uint(a), tag, __float_as_uint(b), tag};
+    const u32x4 hi = {__float_as_uint(c), tag, __float_as_uint(d), tag};
+    __builtin_amdgcn_raw_buffer_store_b128(lo, rs, float_off * 4u, 0, 16 /* sc1 */);
+    __builtin_amdgcn_raw_buffer_store_b128(hi, rs, float_off * 4u + 16u, 0, 16);
+}
+
+// Bounded wait bookkeeping: a wave that has polled PD_SPIN_LIMIT times sets the launch's abort word and goes on
+// with what it has; every wave looks at the abort word now and then and stops waiting once it is set.
+struct Spin {
+    unsigned* abort_word;
+    unsigned n;
+    bool dead;
+    __device__ __forceinline__ bool give_up() {
+        if (dead) return true;
+        ++n;
+        if ((n & 1023u) == 0u) {
+            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) dead = true;
+            if (n >= PD_SPIN_LIMIT) {
+                __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dead = true;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+        return dead;
+    }
+};
+
+// One stage's matrix product for this workgroup's 16x16 tile: wave w owns k16-steps [w*CH, (w+1)*CH), fetched
+// (and re-fetched until every granule carries the expected tag) PD_BATCH steps at a time.
+// Returns the reduced tile fragment in wave 0 (lane: column b = lane&15, rows 4*(lane>>4)..+3).
+template <int CH>
+__device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_rsrc_t rs, unsigned off0, unsigned tag0,
+                                        int k16_0, unsigned off1, unsigned tag1, int nk16, int Bpad, int lb, int lq,
+                                        int wave, int lane, f32x4* red, Spin& spin) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < CH; h += PD_BATCH) {
+        GQuad g[PD_BATCH];
+        while (true) {
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < PD_BATCH; ++i) {
+                const int ks = wave * CH + h + i;
+                if (h + i < CH && ks < nk16) {
+                    const bool first = ks < k16_0;
+                    const unsigned fo = first ? off0 + (unsigned)((4 * ks + lq) * Bpad + lb) * 8u
+                                              : off1 + (unsigned)((4 * (ks - k16_0) + lq) * Bpad + lb) * 8u;
+                    g[i] = pd_ldg(rs, fo);
+                    ok = ok && gq_ok(g[i], first ? tag0 : tag1);
+                }
+            }
+            if (__all(ok) || spin.give_up()) break;
+        }
+#pragma unroll
+        for (int i = 0; i < PD_BATCH; ++i) {
+            const int ks = wave * CH + h + i;
+            if (h + i < CH && ks < nk16) {
+                const f32x4 x = gq_val(g[i]);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[h + i].x, x.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[h + i].y, x.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[h + i].z, x.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[h + i].w, x.w, acc1, 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                       // previous readers of `red` are done
+    red[wave * 64 + lane] = acc0 + acc1;
+    __syncthreads();
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (wave == 0) {
+        v = red[lane];
+#pragma unroll
+        for (int ww = 1; ww < PD_WAVES; ++ww) v += red[ww * 64 + lane];
+    }
+    return v;
+}
+
+// one quad with a tag wait (epilogue operands)
+__device__ __forceinline__ f32x4 pd_wait_quad(__amdgpu_buffer_rsrc_t rs, unsigned float_off, unsigned tag, Spin& spin) {
+    GQuad g;
+    while (true) {
+        g = pd_ldg(rs, float_off);
+        if (__all(gq_ok(g, tag)) || spin.give_up()) break;
+    }
+    return gq_val(g);
+}
+
+template <int CH>
+__device__ __forceinline__ void pd_load_w(float4 (&w)[CH], const float* Wp, int tile, int ntiles, int nk16, int wave,
+                                          int lane) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int ks = wave * CH + i;
+        w[i] = (tile < ntiles && ks < nk16)
+                   ? reinterpret_cast<const float4*>(Wp)[((size_t)tile * nk16 + ks) * 64 + lane]
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+__device__ __forceinline__ f32x4 sig4(f32x4 v) { return f32x4{dsigmoid(v.x), dsigmoid(v.y), dsigmoid(v.z), dsigmoid(v.w)}; }
+__device__ __forceinline__ f32x4 tanh4(f32x4 v) { return f32x4{dtanh(v.x), dtanh(v.y), dtanh(v.z), dtanh(v.w)}; }
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+    return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+}
+
+__global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // LDS carve (all offsets multiples of 16)
+    f32x4* red = reinterpret_cast<f32x4*>(smem);                         // [4][64] f32x4 (also ctx partials), 8 KB reserved
+    float* bias_s = reinterpret_cast<float*>(smem + 8192);               // [ST_COUNT][16]
+    float* e_s = bias_s + ST_COUNT * 16;                                 // [T_in rounded to 4]
+    const int T4 = (a.T_in + 3) & ~3;
+    float* keys_s = e_s + T4;                                            // [Th][256] when staged
+    const int Th = (a.T_in + 1) >> 1;
+    float* vals_s = keys_s + (a.lds_keys ? Th * 256 : 0);                // [T_in][128] when staged
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bt = blockIdx.x >> 5, j = blockIdx.x & 31;
+    const int b0 = bt * 16, Bpad = a.Bpad;
+    const int lb = b0 + (lane & 15), lq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.region, 0, a.region_bytes, 0x00020000);
+    Spin spin{reinterpret_cast<unsigned*>(a.sync) + 1, 0u, false};
+
+    // ---- resident weights: this workgroup's tile of every stage, this wave's K chunk
+    float4 w_pre1[6], w_pre2[4], w_attg[6], w_attc[6], w_q[4], w_proj[8], w_g1g[8], w_g1c[8], w_g2g[8], w_g2c[8], w_out[4];
+    pd_load_w<6>(w_pre1, a.Wp[ST_PRE1], j, 16, 21, wave, lane);
+    pd_load_w<4>(w_pre2, a.Wp[ST_PRE2], j, 8, 16, wave, lane);
+    pd_load_w<6>(w_attg, a.Wp[ST_ATTG], j, 32, 24, wave, lane);
+    pd_load_w<6>(w_attc, a.Wp[ST_ATTC], j, 16, 24, wave, lane);
+    pd_load_w<4>(w_q, a.Wp[ST_QUERY], j, 16, 16, wave, lane);
+    pd_load_w<8>(w_proj, a.Wp[ST_PROJ], j, 16, 32, wave, lane);
+    pd_load_w<8>(w_g1g, a.Wp[ST_G1G], j, 32, 32, wave, lane);
+    pd_load_w<8>(w_g1c, a.Wp[ST_G1C], j, 16, 32, wave, lane);
+    pd_load_w<8>(w_g2g, a.Wp[ST_G2G], j, 32, 32, wave, lane);
+    pd_load_w<8>(w_g2c, a.Wp[ST_G2C], j, 16, 32, wave, lane);
+    pd_load_w<4>(w_out, a.Wp[ST_OUT], j, 25, 16, wave, lane);
+    {
+        constexpr int NT[ST_COUNT] = {16, 8, 32, 16, 16, 16, 32, 16, 32, 16, 25};
+        for (int i = tid; i < ST_COUNT * 16; i += PD_THREADS) {
+            const int st = i >> 4, r = i & 15;
+            bias_s[i] = (a.bias[st] && j < NT[st]) ? a.bias[st][j * 16 + r] : 0.f;
+        }
+    }
+    // ---- attention role: utterance u of the group, half `hf` (keys: half of T_in; values: half of the channels)
+    const int u_loc = j >> 1, hf = j & 1;
+    const int b_att = b0 + u_loc;
+    const bool att_on = b_att < a.B;
+    const int t_lo = hf ? Th : 0, t_n = hf ? a.T_in - Th : Th;           // this half's score range
+    const float* keys_g = a.keys + ((size_t)(att_on ? b_att : 0) * a.T_in + t_lo) * 256;
+    const float* vals_g = a.values + (size_t)(att_on ? b_att : 0) * a.T_in * 256 + hf * 128;
+    if (att_on) {
+        if (a.lds_keys)
+            for (int i = tid; i < t_n * 64; i += PD_THREADS)
+                reinterpret_cast<float4*>(keys_s)[i] = reinterpret_cast<const float4*>(keys_g)[i];
+        if (a.lds_vals)
+            for (int i = tid; i < a.T_in * 32; i += PD_THREADS)
+                reinterpret_cast<float4*>(vals_s)[i] =
+                    reinterpret_cast<const float4*>(vals_g + (size_t)(i >> 5) * 256)[i & 31];
+    }
+    const float4 v_att = reinterpret_cast<const float4*>(a.attn_v)[lane];
+    __syncthreads();
+
+    // tiles this workgroup owns across steps (wave 0 only uses them)
+    f32x4 hatt_t = {0.f, 0.f, 0.f, 0.f}, h1_t = hatt_t, h2_t = hatt_t, d0_t = hatt_t, o1_t = hatt_t;
+    const unsigned te = (unsigned)((j * 4 + lq) * Bpad + lb) * 8u;             // float offset of this lane's quad in tile j
+    const unsigned te_hi = (unsigned)(((j >= 16 ? j - 16 : 0) * 4 + lq) * Bpad + lb) * 8u;   // tile j-16 (u half of a gates stage)
+    const unsigned st_stride = (unsigned)(256 * Bpad * 2);                      // one 256-wide G-layout buffer
+#ifdef PD_STAMPS
+    int stamp_i = 0;
+#define PD_STAMP() do { if (blockIdx.x == 0 && s == 5 && tid == 0 && stamp_i < 64) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); a.dbg[stamp_i++] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define PD_STAMP() do {} while (0)
+#endif
+#define PD_BIAS(st) (*reinterpret_cast<const f32x4*>(bias_s + (st) * 16 + 4 * lq))
+#define PD_MMA(CH, W, o0, t0, k0, o1, t1, nk) pd_mma<CH>(W, rs, o0, t0, k0, o1, t1, nk, Bpad, lb, lq, wave, lane, red, spin)
+
+    for (int s = 0; s < a.S; ++s) {
+        const unsigned T = (unsigned)(PD_STAGES * s);                 // tag of stage i of this step = T + i + 1
+        const unsigned Tp = s ? T - PD_STAGES : 0u;                   // previous step (tags below are 0 at s == 0)
+        const unsigned cur = (unsigned)(s & 1) * st_stride, prv = (unsigned)((s & 1) ^ 1) * st_stride;
+        PD_STAMP();
+        const unsigned o_prev = s == 0 ? a.o_go : a.o_outQ + (unsigned)((s - 1) * 400 + 320) * Bpad * 2u;
+        // ---- stage 0/1: decoder prenet (rnn_wrappers.py:25): relu(W1 [prev; ctx] + b1), relu(W2 . + b2)
+        if (j < 16) {
+            f32x4 v = PD_MMA(6, w_pre1, o_prev, s ? Tp + 13u : 0u, 5, a.o_ctx, s ? Tp + 7u : 0u, 21);
+            if (wave == 0) pd_stg(rs, a.o_p1 + te, relu4(v + PD_BIAS(ST_PRE1)), T + 1u);
+        }
+        PD_STAMP();
+        if (j < 8) {
+            f32x4 v = PD_MMA(4, w_pre2, a.o_p1, T + 1u, 16, 0u, 0u, 16);
+            if (wave == 0) pd_stg(rs, a.o_p2 + te, relu4(v + PD_BIAS(ST_PRE2)), T + 2u);
+        }
+        PD_STAMP();
+        // ---- stage 2/3: attention GRU (rnn_wrappers.py:26): gates, then candidate + state update
+        {
+            f32x4 v = PD_MMA(6, w_attg, a.o_p2, T + 2u, 8, a.o_hatt + prv, s ? Tp + 4u : 0u, 24);
+            if (wave == 0) {
+                const f32x4 g = sig4(v + PD_BIAS(ST_ATTG));
+                if (j < 16) pd_stg(rs, a.o_rh + te, g * hatt_t, T + 3u);
+                else pd_stg(rs, a.o_u + te_hi, g, T + 3u);
+            }
+        }
+        PD_STAMP();
+        if (j < 16) {
+            f32x4 v = PD_MMA(6, w_attc, a.o_p2, T + 2u, 8, a.o_rh, T + 3u, 24);
+            if (wave == 0) {
+                const f32x4 ug = pd_wait_quad(rs, a.o_u + te, T + 3u, spin);
+                const f32x4 c = tanh4(v + PD_BIAS(ST_ATTC));
+                hatt_t = ug * hatt_t + (1.f - ug) * c;
+                pd_stg(rs, a.o_hatt + cur + te, hatt_t, T + 4u);
+            }
+        }
+        PD_STAMP();
+        // ---- stage 4..6: Bahdanau attention (decoder.py:20): query, scores, softmax, context
+        if (j < 16) {
+            f32x4 v = PD_MMA(4, w_q, a.o_hatt + cur, T + 4u, 16, 0u, 0u, 16);
+            if (wave == 0) pd_stg(rs, a.o_q + te, v, T + 5u);
+        }
+        PD_STAMP();
+        if (!att_on) {
+            // padded column of the last 16-utterance tile: no attention, but its context quads must still carry this
+            // step's tag for the stages that read whole tiles (ordered after q, like the real ones)
+            (void)pd_wait_quad(rs, a.o_q + (unsigned)(lane * Bpad + b_att) * 8u, T + 5u, spin);
+            if (tid < 32)
+                pd_stg(rs, a.o_ctx + (unsigned)((hf * 32 + tid) * Bpad + b_att) * 8u, f32x4{0.f, 0.f, 0.f, 0.f}, T + 7u);
+        }
+        if (att_on) {
+            // scores of this half: e_t = sum_d v_d tanh(keys[t,d] + q_d); lane owns dims 4*lane..+3, wave owns t
+            const f32x4 qq = pd_wait_quad(rs, a.o_q + (unsigned)(lane * Bpad + b_att) * 8u, T + 5u, spin);
+            for (int t = wave; t < t_n; t += 2 * PD_WAVES) {
+                const int t1 = t + PD_WAVES;
+                const float4 k0 = a.lds_keys ? reinterpret_cast<const float4*>(keys_s)[t * 64 + lane]
+                                             : reinterpret_cast<const float4*>(keys_g)[t * 64 + lane];
+                float4 k1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t1 < t_n)
+                    k1 = a.lds_keys ? reinterpret_cast<const float4*>(keys_s)[t1 * 64 + lane]
+                                    : reinterpret_cast<const float4*>(keys_g)[t1 * 64 + lane];
+                float s0 = v_att.x * fast_tanh(k0.x + qq.x) + v_att.y * fast_tanh(k0.y + qq.y) +
+                           v_att.z * fast_tanh(k0.z + qq.z) + v_att.w * fast_tanh(k0.w + qq.w);
+                float s1 = v_att.x * fast_tanh(k1.x + qq.x) + v_att.y * fast_tanh(k1.y + qq.y) +
+                           v_att.z * fast_tanh(k1.z + qq.z) + v_att.w * fast_tanh(k1.w + qq.w);
+                s0 = wave_sum(s0);
+                s1 = wave_sum(s1);
+                if (lane == 0) {
+                    const unsigned eo = a.o_e + (unsigned)(b_att * a.T_in + t_lo + t) * 2u;
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(s0), T + 6u}, rs, eo * 4u, 0, 16);
+                    if (t1 < t_n)
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(s1), T + 6u}, rs,
+                                                              (eo + 2u * PD_WAVES) * 4u, 0, 16);
+                }
+            }
+            PD_STAMP();
+            // all T_in scores (both halves) -> LDS
+            __syncthreads();                       // e_s free (previous step's context done)
+            for (int t0 = 0; t0 < a.T_in; t0 += PD_THREADS) {
+                const int t = t0 + tid;
+                u32x2 g = {0u, T + 6u};
+                while (true) {
+                    if (t < a.T_in)
+                        g = __builtin_amdgcn_raw_buffer_load_b64(rs, (a.o_e + (unsigned)(b_att * a.T_in + t) * 2u) * 4u, 0, 16);
+                    if (__all(g.y == T + 6u) || spin.give_up()) break;
+                }
+                if (t < a.T_in) e_s[t] = __uint_as_float(g.x);
+            }
+            __syncthreads();
+            PD_STAMP();
+            if (wave == 0) {   // softmax over all T_in (max-subtracted, as tf.nn.softmax); both halves compute it
+                float mx = -INFINITY;
+                for (int t = lane; t < a.T_in; t += 64) mx = fmaxf(mx, e_s[t]);
+                mx = wave_max(mx);
+                float sum = 0.f;
+                for (int t = lane; t < a.T_in; t += 64) {
+                    const float p = expf(e_s[t] - mx);
+                    e_s[t] = p;
+                    sum += p;
+                }
+                sum = wave_sum(sum);
+                const float inv = 1.f / sum;
+                float* arow = a.alignS + ((size_t)s * a.B + b_att) * a.T_in;
+                for (int t = lane; t < a.T_in; t += 64) {
+                    const float p = e_s[t] * inv;
+                    e_s[t] = p;
+                    if (hf == 0) arow[t] = p;
+                }
+            }
+            __syncthreads();
+            PD_STAMP();
+            // context, this half's 128 channels: lane = (t parity, channel quad), waves stride t by 8
+            const int dq = lane & 31, tp = lane >> 5;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int t = 2 * wave + tp; t < a.T_in; t += 2 * PD_WAVES) {
+                const float4 x = a.lds_vals ? reinterpret_cast<const float4*>(vals_s)[t * 32 + dq]
+                                            : reinterpret_cast<const float4*>(vals_g + (size_t)t * 256)[dq];
+                const float p = e_s[t];
+                acc.x = fmaf(p, x.x, acc.x); acc.y = fmaf(p, x.y, acc.y);
+                acc.z = fmaf(p, x.z, acc.z); acc.w = fmaf(p, x.w, acc.w);
+            }
+            acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32);
+            acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+            if (lane < 32) red[wave * 32 + lane] = acc;
+            __syncthreads();
+            if (tid < 32) {
+                f32x4 c = red[tid];
+#pragma unroll
+                for (int ww = 1; ww < PD_WAVES; ++ww) c += red[ww * 32 + tid];
+                pd_stg(rs, a.o_ctx + (unsigned)((hf * 32 + tid) * Bpad + b_att) * 8u, c, T + 7u);
+            }
+            PD_STAMP();
+        }
+        // ---- stage 7: concat([h_att, ctx]) -> decoder depth (rnn_wrappers.py:53, decoder.py:29)
+        if (j < 16) {
+            f32x4 v = PD_MMA(8, w_proj, a.o_hatt + cur, T + 4u, 16, a.o_ctx, T + 7u, 32);
+            if (wave == 0) {
+                d0_t = v + PD_BIAS(ST_PROJ);
+                pd_stg(rs, a.o_d0 + te, d0_t, T + 8u);
+            }
+        }
+        PD_STAMP();
+        // ---- stage 8/9: residual GRU 1 (decoder.py:30)
+        {
+            f32x4 v = PD_MMA(8, w_g1g, a.o_d0, T + 8u, 16, a.o_h1 + prv, s ? Tp + 10u : 0u, 32);
+            if (wave == 0) {
+                const f32x4 g = sig4(v + PD_BIAS(ST_G1G));
+                if (j < 16) pd_stg(rs, a.o_rh + st_stride + te, g * h1_t, T + 9u);
+                else pd_stg(rs, a.o_u + st_stride + te_hi, g, T + 9u);
+            }
+        }
+        PD_STAMP();
+        if (j < 16) {
+            f32x4 v = PD_MMA(8, w_g1c, a.o_d0, T + 8u, 16, a.o_rh + st_stride, T + 9u, 32);
+            if (wave == 0) {
+                const f32x4 ug = pd_wait_quad(rs, a.o_u + st_stride + te, T + 9u, spin);
+                const f32x4 c = tanh4(v + PD_BIAS(ST_G1C));
+                h1_t = ug * h1_t + (1.f - ug) * c;
+                o1_t = h1_t + d0_t;
+                pd_stg(rs, a.o_h1 + cur + te, h1_t, T + 10u);
+                pd_stg(rs, a.o_o1 + te, o1_t, T + 10u);
+            }
+        }
+        PD_STAMP();
+        // ---- stage 10/11: residual GRU 2 (decoder.py:31)
+        {
+            f32x4 v = PD_MMA(8, w_g2g, a.o_o1, T + 10u, 16, a.o_h2 + prv, s ? Tp + 12u : 0u, 32);
+            if (wave == 0) {
+                const f32x4 g = sig4(v + PD_BIAS(ST_G2G));
+                if (j < 16) pd_stg(rs, a.o_rh + 2u * st_stride + te, g * h2_t, T + 11u);
+                else pd_stg(rs, a.o_u + 2u * st_stride + te_hi, g, T + 11u);
+            }
+        }
+        PD_STAMP();
+        if (j < 16) {
+            f32x4 v = PD_MMA(8, w_g2c, a.o_o1, T + 10u, 16, a.o_rh + 2u * st_stride, T + 11u, 32);
+            if (wave == 0) {
+                const f32x4 ug = pd_wait_quad(rs, a.o_u + 2u * st_stride + te, T + 11u, spin);
+                const f32x4 c = tanh4(v + PD_BIAS(ST_G2C));
+                h2_t = ug * h2_t + (1.f - ug) * c;
+                pd_stg(rs, a.o_h2 + cur + te, h2_t, T + 12u);
+                pd_stg(rs, a.o_o2 + te, h2_t + o1_t, T + 12u);
+            }
+        }
+        PD_STAMP();
+        // ---- stage 12: r output frames (decoder.py:35); the next step reads its last frame back (helpers.py:77)
+        if (j < 25) {
+            f32x4 v = PD_MMA(4, w_out, a.o_o2, T + 12u, 16, 0u, 0u, 16);
+            if (wave == 0) pd_stg(rs, a.o_outQ + (unsigned)(s * 400) * Bpad * 2u + te, v + PD_BIAS(ST_OUT), T + 13u);
+        }
+        PD_STAMP();
+    }
+#undef PD_MMA
+#undef PD_BIAS
+}
+
+size_t dec_persistent_lds_bytes(int T_in, int* lds_keys, int* lds_vals) {
+    const size_t cap = 160 * 1024;
+    const int T4 = (T_in + 3) & ~3, Th = (T_in + 1) >> 1;
+    size_t base = 8192 + (size_t)ST_COUNT * 16 * 4 + (size_t)T4 * 4;
+    base = (base + 15) & ~(size_t)15;
+    const size_t kb = (size_t)Th * 1024, vb = (size_t)T_in * 512;
+    *lds_keys = base + kb <= cap;
+    *lds_vals = base + (*lds_keys ? kb : 0) + vb <= cap;
+    return base + (*lds_keys ? kb : 0) + (*lds_vals ? vb : 0);
+}
+
+int launch_dec_persistent(DecPersistArgs a, hipStream_t s, Timing* tm) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persistent_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return -1;
+        attr_set = true;
+    }
+    const size_t lds = dec_persistent_lds_bytes(a.T_in, &a.lds_keys, &a.lds_vals);
+    if (tm) tm->begin(KK_DEC_PERSIST, s);
+    hipLaunchKernelGGL(dec_persistent_kernel, dim3(32 * (a.Bpad / 16)), dim3(PD_THREADS), lds, s, a);
+    if (tm) tm->end(KK_DEC_PERSIST, s);
+    return 0;
+}
+
+}  // namespace taco

@@ -16,23 +16,9 @@
 // epilogues for the prenet (ReLU [+dropout replay]), GRU gates (sigmoid, r*h, u), GRU
 // candidate (tanh, state update, residual) and the r-frame output projection (+stop test).
 #include "kernels.h"
+#include "dec_common.h"
 
 namespace taco {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float dsigmoid(float x) { return 1.f / (1.f + expf(-x)); }
-__device__ __forceinline__ float dtanh(float x) {
-    const float e = expf(2.f * x);
-    return 1.f - 2.f / (e + 1.f);
-}
-
-// tanh for the attention scores (T_in*256 evaluations per utterance-step): hardware exp2 + rcp,
-// 1 - 2/(2^(2x log2 e) + 1); absolute error ~2e-7, saturates cleanly. The GRU epilogues keep expf.
-__device__ __forceinline__ float fast_tanh(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
-}
 
 constexpr int DG_WAVES = 8;       // K is split over 8 waves (fixed chunks => fixed summation order)
 constexpr int DG_THREADS = 64 * DG_WAVES;
@@ -133,8 +119,7 @@ __global__ __launch_bounds__(DG_THREADS) void dec_gemm_kernel(DecGemmArgs a) {
             break;
         }
         case DE_OUT: {
-            reinterpret_cast<f32x4*>(a.out)[e] = v;
-            if (lb < a.B && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f)) atomicOr(a.nz + lb, 1);
+            reinterpret_cast<f32x4*>(a.out)[e] = v;   // the stop test reads these back once, in dec_nonzero_kernel
             break;
         }
     }
@@ -155,17 +140,6 @@ void launch_dec_gemm(const DecGemmArgs& a, hipStream_t s, Timing* tm) {
 constexpr int ATTN_THREADS = 1024;
 constexpr int ATTN_WAVES = ATTN_THREADS / 64;
 constexpr int ATTN_DEPTH = 5;     // time steps per wave whose loads are in flight together
-
-__device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    return x;
-}
-__device__ __forceinline__ float wave_max(float x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
-    return x;
-}
 
 __global__ __launch_bounds__(ATTN_THREADS) void dec_attention_kernel(DecAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -267,6 +241,23 @@ void launch_dec_attention(const DecAttnArgs& a, hipStream_t s, Timing* tm) {
 // ---------------------------------------------------------------------------------------
 // Finalisation: stop test bookkeeping, [S][NR/4][Bpad][4] -> mel [B][S*NR],
 // alignS [S][B][T_in] -> align [B][T_in][S] (model/tacotron.py:51).
+// nz[s][b] = any(out[s][:, b] != 0) from the step outputs (stop test of helpers.py:75). `gran` = 1: quads are
+// stored as {x0,tag,x1,tag,x2,tag,x3,tag} (persistent decoder), else plain float4.
+__global__ void dec_nonzero_kernel(const float* __restrict__ outQ, int NRq, int Bpad, int gran, int32_t* __restrict__ nz) {
+    const int s = blockIdx.x;
+    const int qf = gran ? 8 : 4;
+    const float* p = outQ + (size_t)s * NRq * Bpad * qf;
+    for (int b = threadIdx.x; b < Bpad; b += blockDim.x) {
+        int any = 0;
+        for (int r = 0; r < NRq; ++r) {
+            const float* q = p + ((size_t)r * Bpad + b) * qf;
+            if (gran) any |= (q[0] != 0.f) | (q[2] != 0.f) | (q[4] != 0.f) | (q[6] != 0.f);
+            else any |= (q[0] != 0.f) | (q[1] != 0.f) | (q[2] != 0.f) | (q[3] != 0.f);
+        }
+        nz[(size_t)s * Bpad + b] = any;
+    }
+}
+
 __global__ __launch_bounds__(1024) void dec_steps_kernel(const int32_t* __restrict__ nz, int S, int B, int Bpad,
                                                          int32_t* steps_run) {
     // dynamic_decode: finished_b |= all(out_b == 0) (sticky); the loop stops after the first step at which every
@@ -287,7 +278,7 @@ __global__ __launch_bounds__(1024) void dec_steps_kernel(const int32_t* __restri
 }
 
 __global__ void dec_mel_kernel(const float* __restrict__ outQ, const int32_t* __restrict__ steps_run, int S, int NR,
-                               int B, int Bpad, float* __restrict__ mel) {
+                               int B, int Bpad, int gran, float* __restrict__ mel) {
     const int steps = *steps_run;
     const long total = (long)B * S * NR;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -296,7 +287,10 @@ __global__ void dec_mel_kernel(const float* __restrict__ outQ, const int32_t* __
         const int s = (int)(r % S);
         const int b = (int)(r / S);
         float v = 0.f;
-        if (s < steps) v = outQ[(((size_t)s * (NR >> 2) + (n >> 2)) * Bpad + b) * 4 + (n & 3)];
+        if (s < steps) {
+            const size_t q = ((size_t)s * (NR >> 2) + (n >> 2)) * Bpad + b;
+            v = gran ? outQ[q * 8 + 2 * (n & 3)] : outQ[q * 4 + (n & 3)];
+        }
         mel[i] = v;
     }
 }
@@ -314,13 +308,14 @@ __global__ void dec_align_kernel(const float* __restrict__ alignS, const int32_t
     }
 }
 
-void launch_dec_finalize(const float* outQ, const float* alignS, const int32_t* nz, int S, int NR, int B, int Bpad,
+void launch_dec_finalize(const float* outQ, int gran, const float* alignS, int32_t* nz, int S, int NR, int B, int Bpad,
                          int T_in, float* mel, float* align, int32_t* steps_run, hipStream_t s, Timing* tm) {
     if (tm) tm->begin(KK_DEC_MISC, s);
+    hipLaunchKernelGGL(dec_nonzero_kernel, dim3(S), dim3(64), 0, s, outQ, NR / 4, Bpad, gran, nz);
     hipLaunchKernelGGL(dec_steps_kernel, dim3(1), dim3(1024), (size_t)B * 4, s, nz, S, B, Bpad, steps_run);
     long total = (long)B * S * NR;
     int blocks = (int)std::min<long>(2048, (total + 255) / 256);
-    hipLaunchKernelGGL(dec_mel_kernel, dim3(blocks), dim3(256), 0, s, outQ, steps_run, S, NR, B, Bpad, mel);
+    hipLaunchKernelGGL(dec_mel_kernel, dim3(blocks), dim3(256), 0, s, outQ, steps_run, S, NR, B, Bpad, gran, mel);
     total = (long)B * T_in * S;
     blocks = (int)std::min<long>(2048, (total + 255) / 256);
     hipLaunchKernelGGL(dec_align_kernel, dim3(blocks), dim3(256), 0, s, alignS, steps_run, S, B, T_in, align);

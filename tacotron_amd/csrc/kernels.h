@@ -21,6 +21,7 @@ enum KernelKind : int {
     KK_GL_MAG,          // spectrogram de-normalisation
     KK_GL_ITER,         // fused STFT -> phase -> iSTFT Griffin-Lim iteration
     KK_GL_OLA,          // final overlap-add
+    KK_DEC_PERSIST,     // dec_persistent_kernel: the whole decode loop as one launch
     KK_COUNT
 };
 
@@ -83,7 +84,7 @@ struct DecGemmArgs {
     float* h;                         // GATES: reads h; CAND: reads + updates h in place
     const float* res; float* res_out; // CAND: res_out = h_new + res (optional)
     const float* keep; int keep_ld;   // RELU: optional dropout keep flags [B, keep_ld] (+col offset applied)
-    int32_t* nz;                      // OUT: nz[b] |= any(out != 0)
+    int32_t* nz;                      // unused (the stop test scans the outputs afterwards)
 };
 void launch_dec_gemm(const DecGemmArgs& a, hipStream_t s, Timing* tm);
 
@@ -99,8 +100,29 @@ struct DecAttnArgs {
 void launch_dec_attention(const DecAttnArgs& a, hipStream_t s, Timing* tm);
 
 // outQ [S][NR/4][Bpad][4] -> mel [B][S*NR] (zero past steps*NR); alignS [S][B][T_in] -> align [B][T_in][S].
-void launch_dec_finalize(const float* outQ, const float* alignS, const int32_t* nz, int S, int NR, int B, int Bpad,
+void launch_dec_finalize(const float* outQ, int gran, const float* alignS, int32_t* nz, int S, int NR, int B, int Bpad,
                          int T_in, float* mel, float* align, int32_t* steps_run, hipStream_t s, Timing* tm);
+
+// Persistent decoder (dec_persistent.hip), default layer sizes only. Offsets o_* are in floats from `region`,
+// the contiguous, zero-filled block of granule buffers the workgroups exchange through (sc1 stores / loads):
+// a vector of dimension K takes K*Bpad*2 floats; hatt/h1/h2 are double-buffered by step parity (2 x 256 wide),
+// rh and u hold one 256-wide buffer per GRU (3 each), e holds B*T_in {score, tag} pairs, outQ S*400 wide.
+struct DecPersistArgs {
+    const float* Wp[11];      // packed weights per stage: pre1, pre2, attG, attC, query, proj, g1G, g1C, g2G, g2C, out
+    const float* bias[11];    // or null
+    const float* attn_v;
+    const float* keys;        // [B, T_in, 256]
+    const float* values;      // [B, T_in, 256] (encoder outputs)
+    float* region;
+    unsigned region_bytes;
+    unsigned o_go, o_ctx, o_hatt, o_h1, o_h2, o_p1, o_p2, o_rh, o_u, o_q, o_d0, o_o1, o_o2, o_e, o_outQ;
+    float* alignS;            // [S][B][T_in]
+    unsigned long long* sync; // {unused, abort word}, zeroed per call
+    int B, Bpad, T_in, S;
+    int lds_keys, lds_vals;   // filled by the launcher
+    unsigned long long* dbg;  // diagnostic builds (-DPD_STAMPS): s_memrealtime stamps of workgroup 0, step 5
+};
+int launch_dec_persistent(DecPersistArgs a, hipStream_t s, Timing* tm);
 
 // Griffin-Lim
 struct GLPlan {

@@ -92,8 +92,13 @@ class TacoEngine:
     def _s(self):
         return ctypes.c_void_p(self.stream.cuda_stream)
 
-    def set_decode_graph(self, enable):
-        self._check(self.lib.taco_set_decode_graph(self.handle, int(bool(enable))))
+    def set_decode_graph(self, mode):
+        """0/False = eager per-stage kernels, 1/True = hipGraph replay of them, 2 = persistent kernel (default)."""
+        self._check(self.lib.taco_set_decode_graph(self.handle, int(mode)))
+
+    def decode_status(self):
+        """After a synchronisation: raises if the last persistent decode hit a barrier timeout."""
+        self._check(self.lib.taco_decode_status(self.handle))
 
     # ---- stages (tensors in, tensors out; all on self.device)
     def encode(self, ids, lens):
@@ -199,6 +204,7 @@ class TacoEngine:
         """Host-side check of the stop test (helpers.py:75): if dynamic_decode would have stopped
         early, trim and redo the length-dependent stages on the shorter mel."""
         steps = int(o['steps'].item())
+        self.decode_status()
         S = o['alignments'].shape[2]
         if steps < S:
             r = self.hp.outputs_per_step

@@ -21,11 +21,11 @@ def test_library_exports_every_declared_symbol():
     from tacotron_amd import _lib
     lib = _lib.load_library()
     names = _declared_functions()
-    assert len(names) >= 14
+    assert len(names) >= 15
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.EXPORTS) == names
-    assert lib.taco_num_kernel_kinds() == 11
+    assert lib.taco_num_kernel_kinds() == 12
     assert lib.taco_kernel_name(4) == b'dec_gemm'
 
 

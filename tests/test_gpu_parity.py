@@ -84,6 +84,7 @@ def _check_decode(engine, hp, w, enc, S, tag):
     mel_r, al_r, steps_r = O.decode(enc, w64, hp, max_iters=S)
     mel, al, steps = engine.decode(enc.astype(np.float32), max_iters=S)
     mel, al, steps = _np(mel), _np(al), int(_np(steps)[0])
+    engine.decode_status()
     assert steps == steps_r == S
     assert mel.shape == mel_r.shape and al.shape == al_r.shape
     e_mel, e_al = rel_l1(mel, mel_r), rel_l1(al, al_r)
@@ -124,18 +125,41 @@ def test_decode_peaked_attention(hp):
         eng.close()
 
 
-def test_decode_eager_equals_graph(engine, hp):
-    """The captured hipGraph replay and the eager launch sequence are the same kernels: bit-equal."""
+def test_decode_modes_agree(engine, hp):
+    """Mode 1 (captured hipGraph replay) and mode 0 (eager) launch the same per-stage kernels: bit-equal.
+    Mode 2 (persistent kernel, the default) orders its reductions differently: equal to fp32 rounding,
+    and bit-reproducible run to run."""
     import torch
     rng = np.random.default_rng(3)
-    enc = rng.standard_normal((3, 20, 256)).astype(np.float32)
-    engine.set_decode_graph(True)
-    m1, a1, _ = engine.decode(enc, max_iters=7)
-    m1b, a1b, _ = engine.decode(enc, max_iters=7)
-    engine.set_decode_graph(False)
-    m2, a2, _ = engine.decode(enc, max_iters=7)
-    engine.set_decode_graph(True)
+    enc = rng.standard_normal((19, 20, 256)).astype(np.float32)
+    try:
+        engine.set_decode_graph(1)
+        m1, a1, _ = engine.decode(enc, max_iters=7)
+        m1b, a1b, _ = engine.decode(enc, max_iters=7)
+        engine.set_decode_graph(0)
+        m2, a2, _ = engine.decode(enc, max_iters=7)
+        engine.set_decode_graph(2)
+        m3, a3, _ = engine.decode(enc, max_iters=7)
+        m3b, a3b, _ = engine.decode(enc, max_iters=7)
+        torch.cuda.synchronize()
+        engine.decode_status()
+    finally:
+        engine.set_decode_graph(2)
     assert torch.equal(m1, m2) and torch.equal(a1, a2) and torch.equal(m1, m1b)
+    assert torch.equal(m3, m3b) and torch.equal(a3, a3b)
+    assert rel_l1(_np(m3), _np(m1)) < 1e-5 and rel_l1(_np(a3), _np(a1)) < 1e-5
+
+
+@pytest.mark.parametrize('mode', [1, 2])
+def test_decode_parity_per_mode(engine, hp, weights, mode):
+    """Both decode implementations against the oracle (the other decode tests run the default, mode 2)."""
+    rng = np.random.default_rng(77)
+    enc = (0.5 * rng.standard_normal((18, 61, 256))).astype(np.float32).astype(np.float64)
+    try:
+        engine.set_decode_graph(mode)
+        _check_decode(engine, hp, weights, enc, 9, 'mode %d' % mode)
+    finally:
+        engine.set_decode_graph(2)
 
 
 def test_decode_batch_invariance(engine, hp):
@@ -143,10 +167,15 @@ def test_decode_batch_invariance(engine, hp):
     import torch
     rng = np.random.default_rng(4)
     enc = rng.standard_normal((19, 33, 256)).astype(np.float32)
-    m_all, a_all, _ = engine.decode(enc, max_iters=5)
-    for lo, hi in [(0, 1), (3, 10), (16, 19)]:
-        m, a, _ = engine.decode(enc[lo:hi], max_iters=5)
-        assert torch.equal(m, m_all[lo:hi]) and torch.equal(a, a_all[lo:hi])
+    for mode in (2, 1):
+        try:
+            engine.set_decode_graph(mode)
+            m_all, a_all, _ = engine.decode(enc, max_iters=5)
+            for lo, hi in [(0, 1), (3, 10), (16, 19)]:
+                m, a, _ = engine.decode(enc[lo:hi], max_iters=5)
+                assert torch.equal(m, m_all[lo:hi]) and torch.equal(a, a_all[lo:hi]), mode
+        finally:
+            engine.set_decode_graph(2)
 
 
 def test_decode_dropout_replay(engine, hp, weights):
