@@ -976,7 +976,8 @@ extern "C" int taco_decode_status(taco_handle h) {
         unsigned long long st[64];
         HIP_OK(hipMemcpy(st, h->dbg_stamps, sizeof(st), hipMemcpyDeviceToHost));
         fprintf(stderr, "[pd stamps, 10 ns ticks since step start]");
-        for (int i = 1; i < 64 && st[i]; ++i) fprintf(stderr, " %llu", st[i] - st[0]);
+        for (int i = 1; i < 64 && st[i]; ++i)
+            fprintf(stderr, (st[i] >> 62) ? " (%llu)" : " %llu", (st[i] & ~(3ull << 62)) - st[0]);
         fprintf(stderr, "\n");
     }
 #endif

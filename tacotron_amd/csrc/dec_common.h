@@ -19,15 +19,32 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 
+// Wave-wide reductions on the DPP cross-lane path (no LDS round trips: a __shfl_xor butterfly is six dependent
+// ds_bpermute, ~100 cycles each): quad swaps, half-row and row mirrors give every lane its 16-lane row total,
+// the four row totals are combined through readlane. Every lane returns the same value.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    return x;
+    x += dpp_mov<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += dpp_mov<0x4E>(x);    // quad_perm [2,3,0,1]
+    x += dpp_mov<0x141>(x);   // row_half_mirror
+    x += dpp_mov<0x140>(x);   // row_mirror
+    return (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0)) +
+            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32)) +
+            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48)));
 }
 __device__ __forceinline__ float wave_max(float x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
-    return x;
+    x = fmaxf(x, dpp_mov<0xB1>(x));
+    x = fmaxf(x, dpp_mov<0x4E>(x));
+    x = fmaxf(x, dpp_mov<0x141>(x));
+    x = fmaxf(x, dpp_mov<0x140>(x));
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48))));
 }
 
 }  // namespace taco

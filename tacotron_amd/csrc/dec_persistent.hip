@@ -34,8 +34,11 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int PD_THREADS = 256;   // one wave per SIMD: each wave may use the whole 512-entry register file
 constexpr int PD_WAVES = 4;
 constexpr unsigned PD_SPIN_LIMIT = 1u << 21;   // polls (>= ~0.5 us each) before a wait gives up
-constexpr int PD_BATCH = 2;                    // k16-steps fetched (and tag-checked) together
-constexpr int PD_STAGES = 13;                  // hand-off points per decoder step
+constexpr int PD_BATCH = 4;                    // k16-steps fetched (and tag-checked) together
+constexpr int PD_STAGES = 13;
+#ifndef PD_STAMP_WG
+#define PD_STAMP_WG 0
+#endif                  // hand-off points per decoder step
 
 enum { ST_PRE1 = 0, ST_PRE2, ST_ATTG, ST_ATTC, ST_QUERY, ST_PROJ, ST_G1G, ST_G1C, ST_G2G, ST_G2C, ST_OUT, ST_COUNT };
 
@@ -51,6 +54,14 @@ __device__ __forceinline__ GQuad pd_ldg(__amdgpu_buffer_rsrc_t rs, unsigned floa
     GQuad g;
     g.lo = __builtin_amdgcn_raw_buffer_load_b128(rs, float_off * 4u, 0, 16 /* sc1 */);
     g.hi = __builtin_amdgcn_raw_buffer_load_b128(rs, float_off * 4u + 16u, 0, 16);
+    return g;
+}
+// same with the address split into a per-lane byte offset (one VGPR for the whole kernel) and a wave-uniform
+// byte offset (SGPR): the K loop of a stage then needs no address registers at all
+__device__ __forceinline__ GQuad pd_ldg2(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned uni_bytes) {
+    GQuad g;
+    g.lo = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_bytes, uni_bytes, 16 /* sc1 */);
+    g.hi = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_bytes + 16u, uni_bytes, 16);
     return g;
 }
 __device__ __forceinline__ bool gq_ok(const GQuad& g, unsigned tag) {
@@ -75,6 +86,9 @@ struct Spin {
     unsigned* abort_word;
     unsigned n;
     bool dead;
+#ifdef PD_STAMPS
+    unsigned long long* dbg; int stamp_i; bool stamp_on;
+#endif
     __device__ __forceinline__ bool give_up() {
         if (dead) return true;
         ++n;
@@ -91,16 +105,21 @@ struct Spin {
 };
 
 // One stage's matrix product for this workgroup's 16x16 tile: wave w owns k16-steps [w*CH, (w+1)*CH), fetched
-// (and re-fetched until every granule carries the expected tag) PD_BATCH steps at a time.
+// (and re-fetched until every granule carries the expected tag) PD_BATCH steps at a time. Wave 0 can fetch up to
+// two more quads of its epilogue (update gate, residual) in the same poll loop of its first batch.
 // Returns the reduced tile fragment in wave 0 (lane: column b = lane&15, rows 4*(lane>>4)..+3).
-template <int CH>
+struct Extra { unsigned off, tag; f32x4 val; };
+template <int CH, int NX>
 __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_rsrc_t rs, unsigned off0, unsigned tag0,
                                         int k16_0, unsigned off1, unsigned tag1, int nk16, int Bpad, int lb, int lq,
-                                        int wave, int lane, f32x4* red, Spin& spin) {
+                                        int wave_v, int lane, f32x4* red, Spin& spin, Extra* ex) {
+    const int wave = __builtin_amdgcn_readfirstlane(wave_v);              // provably uniform -> scalar addressing
+    const unsigned lane_bytes = (unsigned)(lq * Bpad + lb) * 32u;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int h = 0; h < CH; h += PD_BATCH) {
         GQuad g[PD_BATCH];
+        GQuad gx[NX > 0 ? NX : 1];
         while (true) {
             bool ok = true;
 #pragma unroll
@@ -108,13 +127,24 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
                 const int ks = wave * CH + h + i;
                 if (h + i < CH && ks < nk16) {
                     const bool first = ks < k16_0;
-                    const unsigned fo = first ? off0 + (unsigned)((4 * ks + lq) * Bpad + lb) * 8u
-                                              : off1 + (unsigned)((4 * (ks - k16_0) + lq) * Bpad + lb) * 8u;
-                    g[i] = pd_ldg(rs, fo);
+                    const unsigned uni = first ? (off0 + (unsigned)(4 * ks * Bpad) * 8u) * 4u
+                                               : (off1 + (unsigned)(4 * (ks - k16_0) * Bpad) * 8u) * 4u;
+                    g[i] = pd_ldg2(rs, lane_bytes, uni);
                     ok = ok && gq_ok(g[i], first ? tag0 : tag1);
                 }
             }
+            if (NX > 0 && h == 0 && wave == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    gx[i] = pd_ldg(rs, ex[i].off);
+                    ok = ok && gq_ok(gx[i], ex[i].tag);
+                }
+            }
             if (__all(ok) || spin.give_up()) break;
+        }
+        if (NX > 0 && h == 0 && wave == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) ex[i].val = gq_val(gx[i]);
         }
 #pragma unroll
         for (int i = 0; i < PD_BATCH; ++i) {
@@ -128,6 +158,9 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
             }
         }
     }
+#ifdef PD_STAMPS
+    if (spin.stamp_on && wave_v == 0 && lane == 0 && spin.stamp_i < 60) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); spin.dbg[spin.stamp_i++] = __builtin_amdgcn_s_memrealtime() | (1ull << 62); }
+#endif
     __syncthreads();                       // previous readers of `red` are done
     red[wave * 64 + lane] = acc0 + acc1;
     __syncthreads();
@@ -140,7 +173,7 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
     return v;
 }
 
-// one quad with a tag wait (epilogue operands)
+// one quad with a tag wait
 __device__ __forceinline__ f32x4 pd_wait_quad(__amdgpu_buffer_rsrc_t rs, unsigned float_off, unsigned tag, Spin& spin) {
     GQuad g;
     while (true) {
@@ -173,7 +206,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
     // LDS carve (all offsets multiples of 16)
     f32x4* red = reinterpret_cast<f32x4*>(smem);                         // [4][64] f32x4 (also ctx partials), 8 KB reserved
     float* bias_s = reinterpret_cast<float*>(smem + 8192);               // [ST_COUNT][16]
-    float* e_s = bias_s + ST_COUNT * 16;                                 // [T_in rounded to 4]
+    float* e_s = bias_s + ST_COUNT * 16;                                 // (8 bias slots of 16 used)                                 // [T_in rounded to 4]
     const int T4 = (a.T_in + 3) & ~3;
     float* keys_s = e_s + T4;                                            // [Th][256] when staged
     const int Th = (a.T_in + 1) >> 1;
@@ -185,26 +218,45 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
     const int lb = b0 + (lane & 15), lq = lane >> 4;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.region, 0, a.region_bytes, 0x00020000);
     Spin spin{reinterpret_cast<unsigned*>(a.sync) + 1, 0u, false};
+#ifdef PD_STAMPS
+    spin.dbg = a.dbg; spin.stamp_i = 0; spin.stamp_on = false;
+#endif
 
-    // ---- resident weights: this workgroup's tile of every stage, this wave's K chunk
-    float4 w_pre1[6], w_pre2[4], w_attg[6], w_attc[6], w_q[4], w_proj[8], w_g1g[8], w_g1c[8], w_g2g[8], w_g2c[8], w_out[4];
-    pd_load_w<6>(w_pre1, a.Wp[ST_PRE1], j, 16, 21, wave, lane);
-    pd_load_w<4>(w_pre2, a.Wp[ST_PRE2], j, 8, 16, wave, lane);
-    pd_load_w<6>(w_attg, a.Wp[ST_ATTG], j, 32, 24, wave, lane);
-    pd_load_w<6>(w_attc, a.Wp[ST_ATTC], j, 16, 24, wave, lane);
-    pd_load_w<4>(w_q, a.Wp[ST_QUERY], j, 16, 16, wave, lane);
-    pd_load_w<8>(w_proj, a.Wp[ST_PROJ], j, 16, 32, wave, lane);
-    pd_load_w<8>(w_g1g, a.Wp[ST_G1G], j, 32, 32, wave, lane);
-    pd_load_w<8>(w_g1c, a.Wp[ST_G1C], j, 16, 32, wave, lane);
-    pd_load_w<8>(w_g2g, a.Wp[ST_G2G], j, 32, 32, wave, lane);
-    pd_load_w<8>(w_g2c, a.Wp[ST_G2C], j, 16, 32, wave, lane);
-    pd_load_w<4>(w_out, a.Wp[ST_OUT], j, 25, 16, wave, lane);
-    {
-        constexpr int NT[ST_COUNT] = {16, 8, 32, 16, 16, 16, 32, 16, 32, 16, 25};
-        for (int i = tid; i < ST_COUNT * 16; i += PD_THREADS) {
-            const int st = i >> 4, r = i & 15;
-            bias_s[i] = (a.bias[st] && j < NT[st]) ? a.bias[st][j * 16 + r] : 0.f;
+    // ---- roles. The 32 workgroups of a group split the 16-tile stages between them so that each holds only 52
+    // weight quads per lane (208 registers) and the rest of the register file can keep a whole stage's operands in flight:
+    //   role A (j < 16, k = j): prenet-1 tile k, query tile k, concat-projection tile k (owns d0), GRU-1 owner
+    //        (reset-gate tile k, candidate tile k, owns h1 / o1), update-gate tiles of the attention GRU and of GRU-2,
+    //        output tiles 16..24 (k < 9);
+    //   role B (j >= 16, k = j-16): prenet-2 tile k (k < 8), attention-GRU owner (reset tile k, candidate tile k, owns
+    //        h_att), GRU-2 owner (reset tile k, candidate tile k, owns h2), update-gate tiles of GRU-1, output tiles 0..15.
+    const bool roleA = j < 16;
+    const int k = roleA ? j : j - 16;
+    enum { SL_GATT = 0, SL_G1, SL_G2, SL_X6, SL_X8A, SL_X8B, SL_X4A, SL_X4B, SL_COUNT };
+    float4 wg_att[6], wg_1[8], wg_2[8], wx6[6], wx8a[8], wx8b[8], wx4a[4], wx4b[4];
+    const int t_gatt = roleA ? 16 + k : k, t_g1 = roleA ? k : 16 + k, t_g2 = roleA ? 16 + k : k;
+    const int t_out = roleA ? 16 + k : k;
+    pd_load_w<6>(wg_att, a.Wp[ST_ATTG], t_gatt, 32, 24, wave, lane);
+    pd_load_w<8>(wg_1, a.Wp[ST_G1G], t_g1, 32, 32, wave, lane);
+    pd_load_w<8>(wg_2, a.Wp[ST_G2G], t_g2, 32, 32, wave, lane);
+    pd_load_w<6>(wx6, a.Wp[roleA ? ST_PRE1 : ST_ATTC], k, 16, 24 - (roleA ? 3 : 0), wave, lane);
+    pd_load_w<8>(wx8a, a.Wp[roleA ? ST_PROJ : ST_G2C], k, 16, 32, wave, lane);
+    pd_load_w<8>(wx8b, a.Wp[ST_G1C], k, roleA ? 16 : 0, 32, wave, lane);
+    pd_load_w<4>(wx4a, a.Wp[roleA ? ST_QUERY : ST_PRE2], k, roleA ? 16 : 8, 16, wave, lane);
+    pd_load_w<4>(wx4b, a.Wp[ST_OUT], t_out, 25, 16, wave, lane);
+    for (int i = tid; i < SL_COUNT * 16; i += PD_THREADS) {
+        const int sl = i >> 4, r = i & 15;
+        int st, tile, nt;
+        switch (sl) {
+            case SL_GATT: st = ST_ATTG; tile = t_gatt; nt = 32; break;
+            case SL_G1: st = ST_G1G; tile = t_g1; nt = 32; break;
+            case SL_G2: st = ST_G2G; tile = t_g2; nt = 32; break;
+            case SL_X6: st = roleA ? ST_PRE1 : ST_ATTC; tile = k; nt = 16; break;
+            case SL_X8A: st = roleA ? ST_PROJ : ST_G2C; tile = k; nt = 16; break;
+            case SL_X8B: st = ST_G1C; tile = k; nt = roleA ? 16 : 0; break;
+            case SL_X4A: st = roleA ? ST_QUERY : ST_PRE2; tile = k; nt = roleA ? 16 : 8; break;
+            default: st = ST_OUT; tile = t_out; nt = 25; break;
         }
+        bias_s[i] = (a.bias[st] && tile < nt) ? a.bias[st][tile * 16 + r] : 0.f;
     }
     // ---- attention role: utterance u of the group, half `hf` (keys: half of T_in; values: half of the channels)
     const int u_loc = j >> 1, hf = j & 1;
@@ -225,60 +277,60 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
     const float4 v_att = reinterpret_cast<const float4*>(a.attn_v)[lane];
     __syncthreads();
 
-    // tiles this workgroup owns across steps (wave 0 only uses them)
-    f32x4 hatt_t = {0.f, 0.f, 0.f, 0.f}, h1_t = hatt_t, h2_t = hatt_t, d0_t = hatt_t, o1_t = hatt_t;
-    const unsigned te = (unsigned)((j * 4 + lq) * Bpad + lb) * 8u;             // float offset of this lane's quad in tile j
-    const unsigned te_hi = (unsigned)(((j >= 16 ? j - 16 : 0) * 4 + lq) * Bpad + lb) * 8u;   // tile j-16 (u half of a gates stage)
-    const unsigned st_stride = (unsigned)(256 * Bpad * 2);                      // one 256-wide G-layout buffer
+    // tiles this workgroup owns across steps (wave 0 only uses them): role A h1, d0, o1; role B h_att, h2
+    f32x4 hA_t = {0.f, 0.f, 0.f, 0.f}, hB_t = hA_t, d0_t = hA_t, o1_t = hA_t;   // A: hA=h1 ; B: hA=h_att, hB=h2
+    const unsigned te = (unsigned)((k * 4 + lq) * Bpad + lb) * 8u;          // float offset of this lane's quad in tile k
+    const unsigned te16 = (unsigned)(((16 + k) * 4 + lq) * Bpad + lb) * 8u; // ... in tile 16+k (output frames)
+    const unsigned st_stride = (unsigned)(256 * Bpad * 2);                   // one 256-wide granule buffer
 #ifdef PD_STAMPS
-    int stamp_i = 0;
-#define PD_STAMP() do { if (blockIdx.x == 0 && s == 5 && tid == 0 && stamp_i < 64) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); a.dbg[stamp_i++] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define PD_STAMP() do { spin.stamp_on = (blockIdx.x == PD_STAMP_WG && s == 5); if (spin.stamp_on && tid == 0 && spin.stamp_i < 60) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); a.dbg[spin.stamp_i++] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define PD_STAMP() do {} while (0)
 #endif
-#define PD_BIAS(st) (*reinterpret_cast<const f32x4*>(bias_s + (st) * 16 + 4 * lq))
-#define PD_MMA(CH, W, o0, t0, k0, o1, t1, nk) pd_mma<CH>(W, rs, o0, t0, k0, o1, t1, nk, Bpad, lb, lq, wave, lane, red, spin)
+#define PD_BIAS(sl) (*reinterpret_cast<const f32x4*>(bias_s + (sl) * 16 + 4 * lq))
+#define PD_MMA(CH, NX, W, o0, t0, k0, o1, t1, nk, EX) \
+    pd_mma<CH, NX>(W, rs, o0, t0, k0, o1, t1, nk, Bpad, lb, lq, wave, lane, red, spin, EX)
 
     for (int s = 0; s < a.S; ++s) {
         const unsigned T = (unsigned)(PD_STAGES * s);                 // tag of stage i of this step = T + i + 1
         const unsigned Tp = s ? T - PD_STAGES : 0u;                   // previous step (tags below are 0 at s == 0)
         const unsigned cur = (unsigned)(s & 1) * st_stride, prv = (unsigned)((s & 1) ^ 1) * st_stride;
-        PD_STAMP();
         const unsigned o_prev = s == 0 ? a.o_go : a.o_outQ + (unsigned)((s - 1) * 400 + 320) * Bpad * 2u;
+        Extra ex[2];
+        PD_STAMP();
         // ---- stage 0/1: decoder prenet (rnn_wrappers.py:25): relu(W1 [prev; ctx] + b1), relu(W2 . + b2)
-        if (j < 16) {
-            f32x4 v = PD_MMA(6, w_pre1, o_prev, s ? Tp + 13u : 0u, 5, a.o_ctx, s ? Tp + 7u : 0u, 21);
-            if (wave == 0) pd_stg(rs, a.o_p1 + te, relu4(v + PD_BIAS(ST_PRE1)), T + 1u);
+        if (roleA) {
+            f32x4 v = PD_MMA(6, 0, wx6, o_prev, s ? Tp + 13u : 0u, 5, a.o_ctx, s ? Tp + 7u : 0u, 21, ex);
+            if (wave == 0) pd_stg(rs, a.o_p1 + te, relu4(v + PD_BIAS(SL_X6)), T + 1u);
+        } else if (k < 8) {
+            f32x4 v = PD_MMA(4, 0, wx4a, a.o_p1, T + 1u, 16, 0u, 0u, 16, ex);
+            if (wave == 0) pd_stg(rs, a.o_p2 + te, relu4(v + PD_BIAS(SL_X4A)), T + 2u);
         }
         PD_STAMP();
-        if (j < 8) {
-            f32x4 v = PD_MMA(4, w_pre2, a.o_p1, T + 1u, 16, 0u, 0u, 16);
-            if (wave == 0) pd_stg(rs, a.o_p2 + te, relu4(v + PD_BIAS(ST_PRE2)), T + 2u);
-        }
-        PD_STAMP();
-        // ---- stage 2/3: attention GRU (rnn_wrappers.py:26): gates, then candidate + state update
+        // ---- stage 2/3: attention GRU (rnn_wrappers.py:26): gates (A: update tile, B: reset tile), candidate (B)
         {
-            f32x4 v = PD_MMA(6, w_attg, a.o_p2, T + 2u, 8, a.o_hatt + prv, s ? Tp + 4u : 0u, 24);
+            f32x4 v = PD_MMA(6, 0, wg_att, a.o_p2, T + 2u, 8, a.o_hatt + prv, s ? Tp + 4u : 0u, 24, ex);
             if (wave == 0) {
-                const f32x4 g = sig4(v + PD_BIAS(ST_ATTG));
-                if (j < 16) pd_stg(rs, a.o_rh + te, g * hatt_t, T + 3u);
-                else pd_stg(rs, a.o_u + te_hi, g, T + 3u);
+                const f32x4 g = sig4(v + PD_BIAS(SL_GATT));
+                if (roleA) pd_stg(rs, a.o_u + te, g, T + 3u);
+                else pd_stg(rs, a.o_rh + te, g * hA_t, T + 3u);
             }
         }
         PD_STAMP();
-        if (j < 16) {
-            f32x4 v = PD_MMA(6, w_attc, a.o_p2, T + 2u, 8, a.o_rh, T + 3u, 24);
+        if (!roleA) {
+            ex[0].off = a.o_u + te; ex[0].tag = T + 3u;
+            f32x4 v = PD_MMA(6, 1, wx6, a.o_p2, T + 2u, 8, a.o_rh, T + 3u, 24, ex);
             if (wave == 0) {
-                const f32x4 ug = pd_wait_quad(rs, a.o_u + te, T + 3u, spin);
-                const f32x4 c = tanh4(v + PD_BIAS(ST_ATTC));
-                hatt_t = ug * hatt_t + (1.f - ug) * c;
-                pd_stg(rs, a.o_hatt + cur + te, hatt_t, T + 4u);
+                const f32x4 ug = ex[0].val;
+                const f32x4 c = tanh4(v + PD_BIAS(SL_X6));
+                hA_t = ug * hA_t + (1.f - ug) * c;
+                pd_stg(rs, a.o_hatt + cur + te, hA_t, T + 4u);
             }
         }
         PD_STAMP();
-        // ---- stage 4..6: Bahdanau attention (decoder.py:20): query, scores, softmax, context
-        if (j < 16) {
-            f32x4 v = PD_MMA(4, w_q, a.o_hatt + cur, T + 4u, 16, 0u, 0u, 16);
+        // ---- stage 4..6: Bahdanau attention (decoder.py:20): query (A), scores, softmax, context (all)
+        if (roleA) {
+            f32x4 v = PD_MMA(4, 0, wx4a, a.o_hatt + cur, T + 4u, 16, 0u, 0u, 16, ex);
             if (wave == 0) pd_stg(rs, a.o_q + te, v, T + 5u);
         }
         PD_STAMP();
@@ -360,74 +412,76 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
                 acc.x = fmaf(p, x.x, acc.x); acc.y = fmaf(p, x.y, acc.y);
                 acc.z = fmaf(p, x.z, acc.z); acc.w = fmaf(p, x.w, acc.w);
             }
-            acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32);
-            acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
-            if (lane < 32) red[wave * 32 + lane] = acc;
+            red[wave * 64 + lane] = acc;
             __syncthreads();
             if (tid < 32) {
-                f32x4 c = red[tid];
+                f32x4 c = red[tid] + red[32 + tid];
 #pragma unroll
-                for (int ww = 1; ww < PD_WAVES; ++ww) c += red[ww * 32 + tid];
+                for (int ww = 1; ww < PD_WAVES; ++ww) c += red[ww * 64 + tid] + red[ww * 64 + 32 + tid];
                 pd_stg(rs, a.o_ctx + (unsigned)((hf * 32 + tid) * Bpad + b_att) * 8u, c, T + 7u);
             }
             PD_STAMP();
         }
-        // ---- stage 7: concat([h_att, ctx]) -> decoder depth (rnn_wrappers.py:53, decoder.py:29)
-        if (j < 16) {
-            f32x4 v = PD_MMA(8, w_proj, a.o_hatt + cur, T + 4u, 16, a.o_ctx, T + 7u, 32);
+        // ---- stage 7: concat([h_att, ctx]) -> decoder depth (rnn_wrappers.py:53, decoder.py:29)  (A, owns d0)
+        if (roleA) {
+            f32x4 v = PD_MMA(8, 0, wx8a, a.o_hatt + cur, T + 4u, 16, a.o_ctx, T + 7u, 32, ex);
             if (wave == 0) {
-                d0_t = v + PD_BIAS(ST_PROJ);
+                d0_t = v + PD_BIAS(SL_X8A);
                 pd_stg(rs, a.o_d0 + te, d0_t, T + 8u);
             }
         }
         PD_STAMP();
-        // ---- stage 8/9: residual GRU 1 (decoder.py:30)
+        // ---- stage 8/9: residual GRU 1 (decoder.py:30): gates (A: reset tile, B: update tile), candidate (A)
         {
-            f32x4 v = PD_MMA(8, w_g1g, a.o_d0, T + 8u, 16, a.o_h1 + prv, s ? Tp + 10u : 0u, 32);
+            f32x4 v = PD_MMA(8, 0, wg_1, a.o_d0, T + 8u, 16, a.o_h1 + prv, s ? Tp + 10u : 0u, 32, ex);
             if (wave == 0) {
-                const f32x4 g = sig4(v + PD_BIAS(ST_G1G));
-                if (j < 16) pd_stg(rs, a.o_rh + st_stride + te, g * h1_t, T + 9u);
-                else pd_stg(rs, a.o_u + st_stride + te_hi, g, T + 9u);
+                const f32x4 g = sig4(v + PD_BIAS(SL_G1));
+                if (roleA) pd_stg(rs, a.o_rh + st_stride + te, g * hA_t, T + 9u);
+                else pd_stg(rs, a.o_u + st_stride + te, g, T + 9u);
             }
         }
         PD_STAMP();
-        if (j < 16) {
-            f32x4 v = PD_MMA(8, w_g1c, a.o_d0, T + 8u, 16, a.o_rh + st_stride, T + 9u, 32);
+        if (roleA) {
+            ex[0].off = a.o_u + st_stride + te; ex[0].tag = T + 9u;
+            f32x4 v = PD_MMA(8, 1, wx8b, a.o_d0, T + 8u, 16, a.o_rh + st_stride, T + 9u, 32, ex);
             if (wave == 0) {
-                const f32x4 ug = pd_wait_quad(rs, a.o_u + st_stride + te, T + 9u, spin);
-                const f32x4 c = tanh4(v + PD_BIAS(ST_G1C));
-                h1_t = ug * h1_t + (1.f - ug) * c;
-                o1_t = h1_t + d0_t;
-                pd_stg(rs, a.o_h1 + cur + te, h1_t, T + 10u);
+                const f32x4 ug = ex[0].val;
+                const f32x4 c = tanh4(v + PD_BIAS(SL_X8B));
+                hA_t = ug * hA_t + (1.f - ug) * c;
+                o1_t = hA_t + d0_t;
+                pd_stg(rs, a.o_h1 + cur + te, hA_t, T + 10u);
                 pd_stg(rs, a.o_o1 + te, o1_t, T + 10u);
             }
         }
         PD_STAMP();
-        // ---- stage 10/11: residual GRU 2 (decoder.py:31)
+        // ---- stage 10/11: residual GRU 2 (decoder.py:31): gates (A: update tile, B: reset tile), candidate (B)
         {
-            f32x4 v = PD_MMA(8, w_g2g, a.o_o1, T + 10u, 16, a.o_h2 + prv, s ? Tp + 12u : 0u, 32);
+            f32x4 v = PD_MMA(8, 0, wg_2, a.o_o1, T + 10u, 16, a.o_h2 + prv, s ? Tp + 12u : 0u, 32, ex);
             if (wave == 0) {
-                const f32x4 g = sig4(v + PD_BIAS(ST_G2G));
-                if (j < 16) pd_stg(rs, a.o_rh + 2u * st_stride + te, g * h2_t, T + 11u);
-                else pd_stg(rs, a.o_u + 2u * st_stride + te_hi, g, T + 11u);
+                const f32x4 g = sig4(v + PD_BIAS(SL_G2));
+                if (roleA) pd_stg(rs, a.o_u + 2u * st_stride + te, g, T + 11u);
+                else pd_stg(rs, a.o_rh + 2u * st_stride + te, g * hB_t, T + 11u);
             }
         }
         PD_STAMP();
-        if (j < 16) {
-            f32x4 v = PD_MMA(8, w_g2c, a.o_o1, T + 10u, 16, a.o_rh + 2u * st_stride, T + 11u, 32);
+        if (!roleA) {
+            ex[0].off = a.o_u + 2u * st_stride + te; ex[0].tag = T + 11u;
+            ex[1].off = a.o_o1 + te; ex[1].tag = T + 10u;
+            f32x4 v = PD_MMA(8, 2, wx8a, a.o_o1, T + 10u, 16, a.o_rh + 2u * st_stride, T + 11u, 32, ex);
             if (wave == 0) {
-                const f32x4 ug = pd_wait_quad(rs, a.o_u + 2u * st_stride + te, T + 11u, spin);
-                const f32x4 c = tanh4(v + PD_BIAS(ST_G2C));
-                h2_t = ug * h2_t + (1.f - ug) * c;
-                pd_stg(rs, a.o_h2 + cur + te, h2_t, T + 12u);
-                pd_stg(rs, a.o_o2 + te, h2_t + o1_t, T + 12u);
+                const f32x4 ug = ex[0].val;
+                const f32x4 c = tanh4(v + PD_BIAS(SL_X8A));
+                hB_t = ug * hB_t + (1.f - ug) * c;
+                pd_stg(rs, a.o_h2 + cur + te, hB_t, T + 12u);
+                pd_stg(rs, a.o_o2 + te, hB_t + ex[1].val, T + 12u);
             }
         }
         PD_STAMP();
         // ---- stage 12: r output frames (decoder.py:35); the next step reads its last frame back (helpers.py:77)
-        if (j < 25) {
-            f32x4 v = PD_MMA(4, w_out, a.o_o2, T + 12u, 16, 0u, 0u, 16);
-            if (wave == 0) pd_stg(rs, a.o_outQ + (unsigned)(s * 400) * Bpad * 2u + te, v + PD_BIAS(ST_OUT), T + 13u);
+        if (!roleA || k < 9) {
+            f32x4 v = PD_MMA(4, 0, wx4b, a.o_o2, T + 12u, 16, 0u, 0u, 16, ex);
+            if (wave == 0)
+                pd_stg(rs, a.o_outQ + (unsigned)(s * 400) * Bpad * 2u + (roleA ? te16 : te), v + PD_BIAS(SL_X4B), T + 13u);
         }
         PD_STAMP();
     }

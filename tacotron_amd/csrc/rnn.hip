@@ -9,6 +9,7 @@
 // h' = u*h + (1-u)*c.  With sequence_length, steps t >= len emit 0 and keep the state; the
 // backward cell runs over the first `len` steps reversed (A.6).
 #include "kernels.h"
+#include "dec_common.h"
 
 namespace taco {
 
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(BIGRU_THREADS) void bigru_scan_kernel(
                 a3 = fmaf(wg[4 * i + 3], hv.w, a3);
             }
             float acc = (a0 + a1) + (a2 + a3);
-            acc += __shfl_xor(acc, 1);
+            acc += dpp_mov<0xB1>(acc);             // lane ^ 1 (DPP quad_perm, no LDS round trip)
             if (half == 0) {
                 const float g = sigmoidf_(acc + xg);
                 if (og < H) rh[og] = g * h[og];
@@ -109,8 +110,8 @@ __global__ __launch_bounds__(BIGRU_THREADS) void bigru_scan_kernel(
                 a3 = fmaf(wc[4 * i + 3], rv.w, a3);
             }
             float acc = (a0 + a1) + (a2 + a3);
-            acc += __shfl_xor(acc, 1);
-            acc += __shfl_xor(acc, 2);
+            acc += dpp_mov<0xB1>(acc);             // lane ^ 1
+            acc += dpp_mov<0x4E>(acc);             // lane ^ 2
             if (q == 0) {
                 const float c = tanhf_(acc + xc);
                 const float u = us[oc];

@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tacotron_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libtaco_hip_stamps.so')
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libtaco_hip_stamps%s.so' % os.environ.get('PD_WG', '0'))
 import numpy as np, torch
 from tacotron_amd.engine import TacoEngine
 from tacotron_amd.hparams import HParams
