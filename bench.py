@@ -9,9 +9,10 @@ over one batch whose ids are already resident in HBM. With N>1 every rank runs i
 32 utterances (weak scaling, no collective on the data path); value = all ranks' frames / max-rank time.
 
 Extra objects on the JSON line:
-  roofline     - the kernel family with the largest share of the step, timed with HIP event pairs on the
-                 engine's stream in a separate instrumented pass (taco_timing_begin/end); algorithmic bytes or
-                 flops per launch from DESIGN.md's formulas.
+  roofline     - the kernel family with the largest share of the step (the decode loop): its launches are timed
+                 with HIP event pairs on each engine's stream over the timed region itself (taco_timing_begin/end);
+                 algorithmic bytes per launch from SURVEY.md 8(d) / DESIGN.md. `kernels` holds every family of one
+                 batch run alone in a separate instrumented pass.
   cpu_baseline - the fp32 numpy oracle ("port") timed on this host on a bounded sample of the same workload.
   kernels      - per-family launches / ms of one instrumented step (all families).
 """
@@ -20,6 +21,11 @@ import json
 import os
 import sys
 import time
+
+# More than three independent streams only overlap when the process may open more hardware queues than HIP's
+# default of 4 (measured: 4 streams 5.0M -> 6.2M frames/s with 8). Must be set before the HIP runtime loads.
+if int(os.environ.get('GPU_MAX_HW_QUEUES') or 0) < 8:
+    os.environ['GPU_MAX_HW_QUEUES'] = '8'
 
 import numpy as np
 
@@ -81,6 +87,8 @@ def family_work(hp, B, T_in, S):
         'dec_gemm': ('hbm', (w_step - v_bytes) * S),
         'dec_attention': ('hbm', (attn + v_bytes) * S),
         'decode_graph': ('hbm', (w_step + attn) * S),
+        # roofline.achieved = (W_step + B*attn_bytes) * S / t_decode; one launch runs all S steps
+        'dec_persistent': ('hbm', (w_step + attn) * S),
         # scan: reads the hoisted input projections, writes the outputs, loads its recurrent weights once per WG
         'bigru_scan': ('hbm', rows * (6 * G + 2 * G) * 4 + 2 * B * 2 * (3 * G * G) * 4),
         'highway_combine': ('hbm', 4 * rows * (2 * 128 + 128 + 128) * 4),
@@ -92,7 +100,7 @@ def family_work(hp, B, T_in, S):
     }
 
 
-def cpu_baseline(hp, weights, T_in, S, budget_s=20.0):
+def cpu_baseline(hp, weights, T_in, S, budget_s=15.0):
     """fp32 numpy restatement (oracle/taco_oracle.py) on this host's cores: full hot path
     (encode -> decode -> post-net) on a bounded sample of the workload."""
     from oracle import taco_oracle as O
@@ -112,7 +120,7 @@ def cpu_baseline(hp, weights, T_in, S, budget_s=20.0):
         run()
         n += 1
         el = time.time() - t0
-        if el > budget_s or n >= 5:
+        if el > budget_s:
             break
     frames = n * B * S * hp.outputs_per_step
     return {'value': frames / el, 'unit': 'mel frames/s', 'cores': int(thr), 'kind': 'port',
@@ -123,14 +131,15 @@ def cpu_baseline(hp, weights, T_in, S, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
     ap.add_argument('--t-in', type=int, default=150)
     ap.add_argument('--max-iters', type=int, default=200)
     ap.add_argument('--to-wav', action='store_true', help='include the 60-iteration Griffin-Lim (configs[2])')
-    ap.add_argument('--streams', type=int, default=1,
-                    help='independent batches in flight per GPU: step i runs on engine/stream i %% streams')
+    ap.add_argument('--streams', type=int, default=6,
+                    help='independent batches in flight per GPU: step i runs on engine/stream i %% streams '
+                         '(a serving loop keeps several batches in flight; 1 = strictly one batch at a time)')
     ap.add_argument('--decode-mode', type=int, default=2, help='0 eager per-stage kernels, 1 hipGraph, 2 persistent kernel')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -189,12 +198,25 @@ def main():
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - t0)
     lat_ms = 1e3 * sorted(lat)[len(lat) // 2]
+    # HIP event pairs around every launch of the decode-loop kernel, on each engine's own stream, over the timed
+    # region itself (two event records per batch): the roofline's launch duration is measured live, under the
+    # same contention as `value`
+    loop_fam = {2: 'dec_persistent', 1: 'decode_graph'}.get(args.decode_mode)
+    if loop_fam and not args.no_roofline:
+        for e in engines:
+            e.timing_begin(loop_fam)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     el = time.perf_counter() - t0
+    live_n, live_ms = 0, 0.0
+    if loop_fam and not args.no_roofline:
+        for e in engines:
+            n_, ms_ = e.timing_end()
+            live_n += n_
+            live_ms += ms_
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device=eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -222,25 +244,32 @@ def main():
         work = family_work(hp, B, T_in, S)
         kinds = eng.kernel_kinds()
         fam = {}
-        for k in kinds:
-            if k == 'decode_graph':
-                continue
+
+        def one(k):
+            # one batch alone on engine 0's stream, with HIP event pairs around every launch of family k
             eng.timing_begin(k)
-            step()
+            eng.synthesize(ids, lens, max_iters=S, to_wav=args.to_wav, out=out)
             n, ms = eng.timing_end()
             if n:
                 fam[k] = {'launches': n, 'ms': ms, 'avg_us': 1e3 * ms / n}
-        eng.timing_begin('decode_graph')
-        step()
-        n, ms = eng.timing_end()
-        if n:
-            fam['decode_graph'] = {'launches': n, 'ms': ms, 'avg_us': 1e3 * ms / n}
+
+        # families of the decode mode that is NOT the one benchmarked would only run because asking for their
+        # timing forces the per-stage path: leave them out
+        skip = {'dec_gemm', 'dec_attention', 'decode_graph'} if args.decode_mode == 2 else {'dec_persistent'}
+        for k in kinds:
+            if k not in skip and k != 'decode_graph':
+                one(k)
+        if 'decode_graph' not in skip and args.decode_mode == 1:
+            one('decode_graph')
         res['kernels'] = fam
         leaf = {k: v for k, v in fam.items() if k != 'decode_graph'}
         dom = max(leaf, key=lambda k: leaf[k]['ms'])
         bound, amount = work[dom]
         per_launch = amount / leaf[dom]['launches']
         sec = leaf[dom]['ms'] * 1e-3 / leaf[dom]['launches']
+        solo_us = 1e6 * sec
+        if dom == loop_fam and live_n:
+            sec = live_ms * 1e-3 / live_n          # average over the launches of the timed region
         if bound == 'hbm':
             ach, peak, unit = per_launch / sec / 1e9, HBM_PEAK_GBS, 'GB/s'
         else:
@@ -253,11 +282,14 @@ def main():
             traffic = None
         res['roofline'] = {'kernel': dom, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit,
                            'frac': ach / peak, 'traffic': traffic, 'launches_per_step': leaf[dom]['launches'],
-                           'avg_launch_us': 1e6 * sec, 'algorithmic_per_launch': per_launch}
-        if 'decode_graph' in fam:
-            b, amt = work['decode_graph']
-            s2 = fam['decode_graph']['ms'] * 1e-3
-            res['decode_loop'] = {'ms': fam['decode_graph']['ms'], 'us_per_decoder_step': 1e6 * s2 / S,
+                           'avg_launch_us': 1e6 * sec, 'avg_launch_us_one_batch_in_flight': solo_us,
+                           'launches_timed': live_n if dom == loop_fam and live_n else leaf[dom]['launches'],
+                           'algorithmic_per_launch': per_launch}
+        loop = 'dec_persistent' if 'dec_persistent' in fam else ('decode_graph' if 'decode_graph' in fam else None)
+        if loop:
+            b, amt = work[loop]
+            s2 = fam[loop]['ms'] * 1e-3
+            res['decode_loop'] = {'kernel': loop, 'ms': fam[loop]['ms'], 'us_per_decoder_step': 1e6 * s2 / S,
                                   'achieved_GBps': amt / s2 / 1e9, 'frac_of_hbm': amt / s2 / 1e9 / HBM_PEAK_GBS}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(hp, weights, T_in, S)
