@@ -73,6 +73,7 @@ struct DecW {
 struct CbhgW {
     int in_depth = 0, K = 0, bank_filters = 0, proj1 = 0, proj2 = 0, highway_depth = 0, n_highway = 0, gru = 0;
     std::vector<ConvW> bank;
+    GemmGroup* bank_groups = nullptr;   // device table: the K bank convolutions, widest first (one grouped launch)
     ConvW p1, p2, fix;
     bool has_fix = false;
     std::vector<ConvW> hw;   // N = 2*highway_depth: [H | T]
@@ -194,6 +195,17 @@ struct Loader {
             if (!conv(cb.bank[k - 1], s + "kernel", s + "bias", k, cb.in_depth, cb.bank_filters)) return false;
             const std::string b = scope + "/conv_bank/batch_normalization" + (k == 1 ? "" : "_" + std::to_string(k - 1));
             if (!bn(cb.bank[k - 1], b)) return false;
+        }
+        {
+            std::vector<GemmGroup> gt;
+            for (int k = cb.K; k >= 1; --k) {   // widest (most work) first
+                const ConvW& w = cb.bank[k - 1];
+                gt.push_back(GemmGroup{w.W, w.bias, w.scale, w.shift, w.taps, w.padl, (k - 1) * cb.bank_filters, 0});
+            }
+            std::vector<float> raw((gt.size() * sizeof(GemmGroup) + 3) / 4);
+            memcpy(raw.data(), gt.data(), gt.size() * sizeof(GemmGroup));
+            cb.bank_groups = reinterpret_cast<GemmGroup*>(upload(raw));
+            if (!cb.bank_groups) return false;
         }
         std::string s = scope + "/proj_1/conv1d/";
         // proj width comes from the kernel entry itself
@@ -320,6 +332,8 @@ size_t cbhg_ws_bytes(const CbhgW& cb, size_t M) {
     n += 2 * al(M * cb.highway_depth * 4);     // highway ping-pong
     n += al(M * 2 * cb.highway_depth * 4);     // [H|T]
     n += al(M * 6 * cb.gru * 4);               // rnn input projections
+    const int sk = conv_gemm_pick_splitk((int)M, cb.proj1, cb.p1.taps * cb.p1.Cin / 16);
+    if (sk > 1) n += al((size_t)sk * M * ((cb.proj1 + 63) / 64 * 64) * 4);   // proj_1 split-K partial sums
     return n;
 }
 size_t enc_ws_bytes(const taco_ctx* c, int B, int T_in) {
@@ -363,19 +377,23 @@ int run_cbhg(taco_ctx* c, const CbhgW& cb, const float* x, const int32_t* lens, 
     float* hwB = ws.take<float>((size_t)M * cb.highway_depth);
     float* HT = ws.take<float>((size_t)M * 2 * cb.highway_depth);
     float* xp = ws.take<float>((size_t)M * 6 * cb.gru);
+    const int sk = conv_gemm_pick_splitk(M, cb.proj1, cb.p1.taps * cb.p1.Cin / 16);
+    float* p1part = sk > 1 ? ws.take<float>((size_t)sk * M * ((cb.proj1 + 63) / 64 * 64)) : nullptr;
     if (!ws.ok()) return fail("workspace too small (need >= %zu bytes)", ws.off);
     const int ldb = cb.K * cb.bank_filters;
+    if ((size_t)M * std::max(ldb, 6 * cb.gru) * 4 >= ((size_t)1 << 31))
+        return fail("B*T = %d too large for 32-bit operand offsets (row width %d)", M, ldb);
     GemmArgs g;
-    // conv bank (modules.py:63-67): ReLU inside the conv, then BN
-    for (int k = 0; k < cb.K; ++k) {
-        const ConvW& w = cb.bank[k];
-        g = GemmArgs{x, cb.in_depth, M, T, w.Cin, w.taps, w.padl, w.W, w.ldw, w.N, w.bias, w.scale, w.shift,
-                     nullptr, 0, bank + (size_t)k * cb.bank_filters, ldb, ACT_RELU, 0};
+    // conv bank (modules.py:63-67): ReLU inside the conv, then BN; the K convolutions are one grouped launch
+    {
+        const ConvW& w = cb.bank[0];
+        g = GemmArgs{x, cb.in_depth, M, T, w.Cin, 1, 0, nullptr, w.ldw, w.N, nullptr, nullptr, nullptr,
+                     nullptr, 0, bank, ldb, ACT_RELU, 0, cb.bank_groups, cb.K, nullptr, 0};
         launch_conv_gemm(g, s, tm);
     }
     // max-pool (modules.py:70-71) folded into proj_1's loader; proj_1 ReLU + BN (modules.py:74-75)
     g = GemmArgs{bank, ldb, M, T, cb.p1.Cin, cb.p1.taps, cb.p1.padl, cb.p1.W, cb.p1.ldw, cb.p1.N, cb.p1.bias,
-                 cb.p1.scale, cb.p1.shift, nullptr, 0, p1, cb.proj1, ACT_RELU, 1};
+                 cb.p1.scale, cb.p1.shift, nullptr, 0, p1, cb.proj1, ACT_RELU, 1, nullptr, 0, p1part, sk};
     launch_conv_gemm(g, s, tm);
     // proj_2 linear + BN, + residual (modules.py:76-80)
     g = GemmArgs{p1, cb.proj1, M, T, cb.p2.Cin, cb.p2.taps, cb.p2.padl, cb.p2.W, cb.p2.ldw, cb.p2.N, cb.p2.bias,
@@ -993,6 +1011,7 @@ extern "C" int taco_debug_conv_gemm(const float* X, int32_t ldx, int32_t M, int3
     if (M < 1 || T < 1 || M % T || Cin < 16 || Cin % 16 || taps < 1 || ldw % 128 || N < 1 || N > ldw || ldx % 4 ||
         ldx < Cin || ldc < N || (scale == nullptr) != (shift == nullptr))
         return fail("taco_debug_conv_gemm: shapes violate the kernel's contract");
+    if ((size_t)M * ldx * 4 >= ((size_t)1 << 31)) return fail("taco_debug_conv_gemm: X larger than 2 GiB");
     GemmArgs g{X, ldx, M, T, Cin, taps, padl, W, ldw, N, bias, scale, shift, R, ldr, C, ldc, act, pool};
     launch_conv_gemm(g, (hipStream_t)stream, nullptr);
     return check_launch("taco_debug_conv_gemm");

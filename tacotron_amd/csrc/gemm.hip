@@ -49,70 +49,95 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     const int wm = (wave >> 1) * WM;
     const int wn = (wave & 1) * WN;
 
-    // per-thread A rows (fixed over the K loop)
-    const float* arow[NA];   // start of this row's sequence (b*T rows in)
-    int at[NA];              // t within the sequence, or -1 for rows past M
-    int arow_l[NA], akq[NA];
+    // a grouped launch runs several convolutions over the same input (the CBHG conv bank) as grid.z slices
+    const float* W = a.W;
+    const float* bias = a.bias;
+    const float* scale = a.scale;
+    const float* shift = a.shift;
+    float* C = a.C;
+    int taps = a.taps, padl = a.padl;
+    if (a.groups) {
+        const GemmGroup g = a.groups[blockIdx.z];
+        W = g.W; bias = g.bias; scale = g.scale; shift = g.shift;
+        taps = g.taps; padl = g.padl;
+        C += g.coff;
+    }
+    // split-K: grid.z slices of the k-tile range, raw partial sums out (splitk_epilogue_kernel finishes)
+    const int nk_all = taps * a.Cin / BK;
+    int kt0 = 0, kt1 = nk_all;
+    if (a.splitk > 1) {
+        kt0 = (int)((long)nk_all * blockIdx.z / a.splitk);
+        kt1 = (int)((long)nk_all * (blockIdx.z + 1) / a.splitk);
+    }
+
+    // A operand through a buffer resource: rows outside [0, T) of their utterance (SAME padding) and rows past M
+    // are fetched at an out-of-range offset, which returns zeros: no branch around a load
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.X), 0, (int)(((size_t)(a.M - 1) * a.ldx + a.Cin) * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned rowoff[NA];     // byte offset of (sequence start row, this thread's k quad)
+    int at[NA];              // t within the sequence, or a value that fails every range test for rows past M
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int f = tid + 256 * i;
-        const int row = f >> 2;
-        arow_l[i] = row;
-        akq[i] = f & 3;
+        const int row = f >> 2, kq = f & 3;
         const int m = m0 + row;
-        if (m < a.M) {
-            const int t = m % a.T;
-            at[i] = t;
-            arow[i] = a.X + (size_t)(m - t) * a.ldx;
-        } else {
-            at[i] = -1;
-            arow[i] = a.X;
-        }
+        const int t = m % a.T;
+        at[i] = m < a.M ? t : -(1 << 20);
+        rowoff[i] = (unsigned)(m - t) * (unsigned)a.ldx * 4u + 16u * kq;
     }
-    const int nk = a.taps * a.Cin / BK;
+    const float* wp[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int f = tid + 256 * i;
+        const int k = f / (BN / 4), nq = f % (BN / 4);
+        wp[i] = W + (size_t)(kt0 * BK + k) * a.ldw + n0 + 4 * nq;
+    }
+    const size_t wstep = (size_t)BK * a.ldw;
+    int tap = (kt0 * BK) / a.Cin, c0 = (kt0 * BK) % a.Cin;     // position of the NEXT tile to fetch
+    const unsigned ldx4 = (unsigned)a.ldx * 4u;
 
-    float4 ra[NA], rb[NB];
-    int tap = 0, c0 = 0;     // position of the NEXT tile to fetch
-    auto fetch = [&]() {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int t2 = at[i] + tap - a.padl;
-            if (at[i] >= 0 && t2 >= 0 && t2 < a.T) {
-                const float* p = arow[i] + (size_t)t2 * a.ldx + c0 + 4 * akq[i];
-                v = *reinterpret_cast<const float4*>(p);
-                if (a.pool && t2 + 1 < a.T) v = max4(v, *reinterpret_cast<const float4*>(p + a.ldx));
-            }
-            ra[i] = v;
-        }
-        const int k0 = tap * a.Cin + c0;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int f = tid + 256 * i;
-            const int k = f / (BN / 4);
-            const int nq = f % (BN / 4);
-            rb[i] = *reinterpret_cast<const float4*>(a.W + (size_t)(k0 + k) * a.ldw + n0 + 4 * nq);
-        }
-        c0 += BK;
-        if (c0 == a.Cin) { c0 = 0; ++tap; }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int k = 4 * akq[i];
-            As[buf][k + 0][arow_l[i]] = ra[i].x;
-            As[buf][k + 1][arow_l[i]] = ra[i].y;
-            As[buf][k + 2][arow_l[i]] = ra[i].z;
-            As[buf][k + 3][arow_l[i]] = ra[i].w;
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int f = tid + 256 * i;
-            const int k = f / (BN / 4);
-            const int nq = f % (BN / 4);
-            *reinterpret_cast<float4*>(&Bs[buf][k][4 * nq]) = rb[i];
-        }
-    };
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v ra[NA], rp[NA];
+    f32x4v rb[NB];
+#define CG_FETCH()                                                                                       \
+    do {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                 \
+            const int t2 = at[i] + tap - padl;                                                           \
+            const bool ok = (unsigned)t2 < (unsigned)a.T;                                                \
+            const unsigned off = rowoff[i] + (unsigned)t2 * ldx4 + (unsigned)c0 * 4u;                    \
+            const unsigned vo = ok ? off : OOB;                                                          \
+            ra[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xr, vo, 0, 0));     \
+            if (a.pool) {                                                                                \
+                const unsigned vo2 = (ok && t2 + 1 < a.T) ? off + ldx4 : vo;                             \
+                rp[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xr, vo2, 0, 0)); \
+            }                                                                                            \
+        }                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                 \
+            rb[i] = *reinterpret_cast<const f32x4v*>(wp[i]);                                             \
+            wp[i] += wstep;                                                                              \
+        }                                                                                                \
+        c0 += BK;                                                                                        \
+        if (c0 == a.Cin) { c0 = 0; ++tap; }                                                              \
+    } while (0)
+#define CG_STASH(buf)                                                                                    \
+    do {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                 \
+            const int f = tid + 256 * i;                                                                 \
+            const int row = f >> 2, k = 4 * (f & 3);                                                     \
+            f32x4v v = ra[i];                                                                            \
+            if (a.pool) v = __builtin_elementwise_max(v, rp[i]);                                         \
+            As[buf][k + 0][row] = v.x;                                                                   \
+            As[buf][k + 1][row] = v.y;                                                                   \
+            As[buf][k + 2][row] = v.z;                                                                   \
+            As[buf][k + 3][row] = v.w;                                                                   \
+        }                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                 \
+            const int f = tid + 256 * i;                                                                 \
+            const int k = f / (BN / 4), nq = f % (BN / 4);                                               \
+            *reinterpret_cast<f32x4v*>(&Bs[buf][k][4 * nq]) = rb[i];                                     \
+        }                                                                                                \
+    } while (0)
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -122,38 +147,70 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    fetch();
-    stash(0);
-    __syncthreads();
     const int lk = lane >> 5, li = lane & 31;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) fetch();
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = As[buf][2 * kk + lk][wm + 32 * i + li];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][2 * kk + lk][wn + 32 * j + li];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) stash(buf ^ 1);
+    // fragments of k-pair kk+1 are read from LDS while the MFMAs of k-pair kk run
+#define CG_COMPUTE(buf)                                                                                  \
+    do {                                                                                                 \
+        float af[BK / 2][TM], bf[BK / 2][TN];                                                            \
+        _Pragma("unroll") for (int kk = 0; kk < BK / 2; ++kk) {                                          \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) af[kk][i] = As[buf][2 * kk + lk][wm + 32 * i + li]; \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[kk][j] = Bs[buf][2 * kk + lk][wn + 32 * j + li]; \
+        }                                                                                                \
+        _Pragma("unroll") for (int kk = 0; kk < BK / 2; ++kk)                                            \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                               \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                           \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0); \
+        /* issue order: the LDS reads of k-pair kk+2 go out before the MFMAs of k-pair kk */             \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                               \
+        _Pragma("unroll") for (int kk = 0; kk < BK / 2; ++kk) {                                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                                     \
+            if (kk + 2 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                      \
+        }                                                                                                \
+    } while (0)
+
+    if (kt1 > kt0) {
+        CG_FETCH();
+        CG_STASH(0);
         __syncthreads();
+        int buf = 0;
+        for (int kt = kt0; kt < kt1 - 1; ++kt) {
+            CG_FETCH();              // tile kt+1 in flight under the MFMAs of tile kt
+            CG_COMPUTE(buf);
+            CG_STASH(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        CG_COMPUTE(buf);
     }
+#undef CG_FETCH
+#undef CG_STASH
+#undef CG_COMPUTE
 
     // epilogue: lane holds column n = ..+(lane&31); rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (a.splitk > 1) {
+        const int ldp = gridDim.x * BN;
+        float* P = a.partial + (size_t)blockIdx.z * a.M * ldp;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn + 32 * j + li;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (m < a.M) P[(size_t)m * ldp + n] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn + 32 * j + li;
         if (n >= a.N) continue;
-        const float bias = a.bias ? a.bias[n] : 0.f;
-        const float sc = a.scale ? a.scale[n] : 1.f;
-        const float sh = a.shift ? a.shift[n] : 0.f;
+        const float bv = bias ? bias[n] : 0.f;
+        const float sc = scale ? scale[n] : 1.f;
+        const float sh = shift ? shift[n] : 0.f;
         const bool second = n >= (a.N >> 1);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -161,25 +218,69 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (m >= a.M) continue;
-                float v = apply_act(acc[i][j][r] + bias, a.act, second);
-                if (a.scale) v = v * sc + sh;
+                float v = apply_act(acc[i][j][r] + bv, a.act, second);
+                if (scale) v = v * sc + sh;
                 if (a.R) v += a.R[(size_t)m * a.ldr + n];
-                a.C[(size_t)m * a.ldc + n] = v;
+                C[(size_t)m * a.ldc + n] = v;
             }
         }
     }
 }
 
-void launch_conv_gemm(const GemmArgs& a, hipStream_t s, Timing* tm) {
+// finishes a split-K launch: sums the slices in a fixed order, then the same epilogue
+__global__ void splitk_epilogue_kernel(GemmArgs a, int ldp) {
+    const long n4 = (long)a.M * (ldp / 4);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / (ldp / 4));
+        const int nb = 4 * (int)(i % (ldp / 4));
+        if (nb >= a.N) continue;
+        float4 sum = *reinterpret_cast<const float4*>(a.partial + (size_t)m * ldp + nb);
+        for (int z = 1; z < a.splitk; ++z) {
+            const float4 p = *reinterpret_cast<const float4*>(a.partial + ((size_t)z * a.M + m) * ldp + nb);
+            sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
+        }
+        const float vs[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = nb + e;
+            if (n >= a.N) break;
+            float v = apply_act(vs[e] + (a.bias ? a.bias[n] : 0.f), a.act, n >= (a.N >> 1));
+            if (a.scale) v = v * a.scale[n] + a.shift[n];
+            if (a.R) v += a.R[(size_t)m * a.ldr + n];
+            a.C[(size_t)m * a.ldc + n] = v;
+        }
+    }
+}
+
+// The split is a function of K alone: an utterance's sums must not depend on how many other utterances share the
+// launch (shard invariance), so M may not influence the reduction order. Only very deep reductions are split (the
+// encoder's proj_1, K = 3*2048), whose M = B*T_in is small in every configuration of interest.
+int conv_gemm_pick_splitk(int M, int N, int nk) {
+    (void)M; (void)N;
+    if (nk < 256) return 1;
+    return std::min(8, nk / 64);
+}
+
+void launch_conv_gemm(const GemmArgs& a_in, hipStream_t s, Timing* tm) {
+    GemmArgs a = a_in;
     if (tm) tm->begin(KK_CONV_GEMM, s);
-    // tile choice: big tiles when they still give >= ~2 blocks per CU, else 64x64
+    const int groups = a.groups ? a.ngroups : 1;
+    if (a.groups || !a.partial) a.splitk = 1;
+    const int z = a.splitk > 1 ? a.splitk : groups;
+    // tile choice: big tiles when one slice alone still gives ~a block per CU, else 64x64
     const long blocks128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (blocks128 >= 384 && a.N >= 128) {
-        dim3 grid((a.N + 127) / 128, (a.M + 127) / 128);
+    if (blocks128 >= 192 && a.N >= 128 && a.splitk == 1) {
+        dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, z);
         hipLaunchKernelGGL((conv_gemm_kernel<128, 128>), grid, dim3(256), 0, s, a);
     } else {
-        dim3 grid((a.N + 63) / 64, (a.M + 63) / 64);
+        dim3 grid((a.N + 63) / 64, (a.M + 63) / 64, z);
         hipLaunchKernelGGL((conv_gemm_kernel<64, 64>), grid, dim3(256), 0, s, a);
+        if (a.splitk > 1) {
+            const int ldp = grid.x * 64;
+            long n4 = (long)a.M * (ldp / 4);
+            int blocks = (int)std::min<long>((n4 + 255) / 256, 2048);
+            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, a, ldp);
+        }
     }
     if (tm) tm->end(KK_CONV_GEMM, s);
 }

@@ -38,6 +38,11 @@ enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3, ACT_
 
 // C[m, n] = epi( sum_{j<taps} sum_{c<Cin} X[b, t+j-padl, c] * W[j*Cin+c, n] ), m = b*T + t.
 // epi(v) = ((act(v + bias[n])) * scale[n] + shift[n]) + R[m, n]   (absent pieces skipped)
+// One convolution of a grouped launch (grid.z): its own weights, taps and output column offset.
+struct GemmGroup {
+    const float* W; const float* bias; const float* scale; const float* shift;
+    int taps, padl, coff, pad_;
+};
 struct GemmArgs {
     const float* X; int ldx;
     int M, T;
@@ -51,7 +56,12 @@ struct GemmArgs {
     float* C; int ldc;
     int act;
     int pool;                     // A operand is max(X[t], X[t+1]) (max_pooling1d 2/1 'same')
+    const GemmGroup* groups;      // device table of ngroups convolutions over the same X (W/bias/scale/shift/taps/padl
+    int ngroups;                  //   above are then ignored; all share Cin, N, ldw, act), or null
+    float* partial;               // split-K scratch of splitk * M * roundup(N, 64) floats, or null
+    int splitk;                   // > 1: K split over grid.z + a reduction/epilogue kernel (conv_gemm_pick_splitk)
 };
+int conv_gemm_pick_splitk(int M, int N, int nk);
 void launch_conv_gemm(const GemmArgs& a, hipStream_t s, Timing* tm);
 
 // y = H*T + x*(1-T) with HT = [relu(H) | sigmoid(T)] rows of width 2*depth
