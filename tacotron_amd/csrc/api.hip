@@ -98,6 +98,7 @@ struct taco_ctx {
     CbhgW enc, post;
     ConvW mem_layer, lin_dense;
     DecW pre1, pre2, att_g, att_c, query, proj, g1_g, g1_c, g2_g, g2_c, outp;
+    DecW pre1_f, g1_g_f, g1_c_f;   // folded forms for the persistent decoder (Loader::dec_fold)
     float* attn_v = nullptr;
     float* twiddle = nullptr;
     float* window = nullptr;
@@ -286,9 +287,7 @@ struct Loader {
         return true;
     }
     // decoder-step weights: [K, N] -> Wp[N/16][K/16][64][4]  (decoder.hip)
-    bool dec(DecW& w, const std::string& kname, const std::string& bname, int K, int N) {
-        const TacoWeightEntry* e = get(kname, {K, N});
-        if (!e) return false;
+    bool dec_pack(DecW& w, const float* data, int K, int N) {
         w.K = K; w.N = N;
         const int nt = N / 16, nk = K / 16;
         std::vector<float> h((size_t)K * N);
@@ -297,10 +296,49 @@ struct Loader {
                 for (int lane = 0; lane < 64; ++lane)
                     for (int cc = 0; cc < 4; ++cc)
                         h[(((size_t)t * nk + ks) * 64 + lane) * 4 + cc] =
-                            e->data[(size_t)(16 * ks + 4 * (lane >> 4) + cc) * N + 16 * t + (lane & 15)];
+                            data[(size_t)(16 * ks + 4 * (lane >> 4) + cc) * N + 16 * t + (lane & 15)];
         w.Wp = upload(h);
+        return w.Wp != nullptr;
+    }
+    bool dec(DecW& w, const std::string& kname, const std::string& bname, int K, int N) {
+        const TacoWeightEntry* e = get(kname, {K, N});
+        if (!e || !dec_pack(w, e->data, K, N)) return false;
         if (!bname.empty()) w.bias = upload_vec(bname, N);
-        return w.Wp && (bname.empty() || w.bias);
+        return bname.empty() || w.bias;
+    }
+    // Folded weights for the persistent decoder: a linear layer L (x -> x Wl + bl, [Kl, Nl]) feeding rows
+    // [0, Nl) of the next layer's kernel Wn ([Nl + Kr, N]) is pre-multiplied into it, so that the next layer reads
+    // L's INPUT and L leaves the step's dependency chain:  [x ; r] -> x (Wl Wn[0:Nl]) + r Wn[Nl:] + (bn + bl Wn[0:Nl]).
+    // `lcol0` selects columns [lcol0, lcol0 + Nl) of Wl / bl (the last of the r output frames). Products in fp64.
+    bool dec_fold(DecW& w, const TacoWeightEntry* Wl, const TacoWeightEntry* bl, int lcol0, int Nl,
+                  const TacoWeightEntry* Wn, const TacoWeightEntry* bn, bool rest_first) {
+        const int Kl = (int)Wl->dims[0], ldl = (int)Wl->dims[1];
+        const int Kn = (int)Wn->dims[0], N = (int)Wn->dims[1], Kr = Kn - Nl;
+        // rows of Wn fed by L: [0, Nl) when the layer's input is [L(x) ; r], [Kr, Kn) when it is [r ; L(x)]
+        const int l0 = rest_first ? Kr : 0, r0 = rest_first ? 0 : Nl;
+        std::vector<float> h((size_t)(Kl + Kr) * N);
+        std::vector<double> acc(N);
+        for (int k = 0; k < Kl; ++k) {
+            std::fill(acc.begin(), acc.end(), 0.0);
+            for (int j = 0; j < Nl; ++j) {
+                const double wl = Wl->data[(size_t)k * ldl + lcol0 + j];
+                const float* wn = Wn->data + (size_t)(l0 + j) * N;
+                for (int n = 0; n < N; ++n) acc[n] += wl * (double)wn[n];
+            }
+            for (int n = 0; n < N; ++n) h[(size_t)k * N + n] = (float)acc[n];
+        }
+        for (int k = 0; k < Kr; ++k)
+            memcpy(&h[(size_t)(Kl + k) * N], Wn->data + (size_t)(r0 + k) * N, (size_t)N * sizeof(float));
+        std::vector<float> bias(N);
+        for (int n = 0; n < N; ++n) {
+            double a = bn ? (double)bn->data[n] : 0.0;
+            if (bl)
+                for (int j = 0; j < Nl; ++j) a += (double)bl->data[lcol0 + j] * (double)Wn->data[(size_t)(l0 + j) * N + n];
+            bias[n] = (float)a;
+        }
+        if (!dec_pack(w, h.data(), Kl + Kr, N)) return false;
+        w.bias = upload(bias);
+        return w.bias != nullptr;
     }
     bool dec_gru(DecW& g, DecW& cnd, const std::string& scope, int in, int H) {
         return dec(g, scope + "gates/kernel", scope + "gates/bias", in + H, 2 * H) &&
@@ -521,6 +559,27 @@ extern "C" int taco_create(const TacoHParams* hp, const TacoWeightEntry* weights
     ok = ok && L.dec_gru(c->g1_g, c->g1_c, DEC + "multi_rnn_cell/cell_1/gru_cell/", p.decoder_depth, p.decoder_depth);
     ok = ok && L.dec_gru(c->g2_g, c->g2_c, DEC + "multi_rnn_cell/cell_2/gru_cell/", p.decoder_depth, p.decoder_depth);
     ok = ok && L.dec(c->outp, DEC + "kernel", DEC + "bias", p.decoder_depth, NR);
+    if (ok) {
+        // persistent decoder: the r-frame output projection folded into the next step's prenet-1 (input
+        // [last frame ; ctx] -> [o2 ; ctx]) and the concat projection folded into GRU-1 (input [d0 ; h] / [d0 ; r.h]
+        // -> [h_att ; ctx ; h] / [h_att ; ctx ; r.h])
+        const int64_t D = p.decoder_depth, A = p.attention_depth;
+        const TacoWeightEntry* Wo = L.get(DEC + "kernel", {D, NR});
+        const TacoWeightEntry* bo = L.get(DEC + "bias", {NR});
+        const TacoWeightEntry* W1 = L.get(DP + "prenet_dense_1/kernel", {p.num_mels + G2, p.prenet_depth1});
+        const TacoWeightEntry* b1 = L.get(DP + "prenet_dense_1/bias", {p.prenet_depth1});
+        const TacoWeightEntry* Wp = L.get(CELL0 + "kernel", {A + G2, D});
+        const TacoWeightEntry* bp = L.get(CELL0 + "bias", {D});
+        const std::string g1s = DEC + "multi_rnn_cell/cell_1/gru_cell/";
+        const TacoWeightEntry* Wg = L.get(g1s + "gates/kernel", {2 * D, 2 * D});
+        const TacoWeightEntry* bg = L.get(g1s + "gates/bias", {2 * D});
+        const TacoWeightEntry* Wc = L.get(g1s + "candidate/kernel", {2 * D, D});
+        const TacoWeightEntry* bc = L.get(g1s + "candidate/bias", {D});
+        ok = Wo && bo && W1 && b1 && Wp && bp && Wg && bg && Wc && bc &&
+             L.dec_fold(c->pre1_f, Wo, bo, NR - p.num_mels, p.num_mels, W1, b1, false) &&
+             L.dec_fold(c->g1_g_f, Wp, bp, 0, (int)D, Wg, bg, false) &&
+             L.dec_fold(c->g1_c_f, Wp, bp, 0, (int)D, Wc, bc, false);
+    }
     ok = ok && L.cbhg(c->post, "post_cbhg");
     ok = ok && L.conv(c->lin_dense, "dense/kernel", "dense/bias", 0, 2 * p.decoder_gru_cells, p.num_freq);
     const TacoWeightEntry* emb = ok ? L.get("embedding", {p.num_chars, p.embedded_depth}) : nullptr;
@@ -788,16 +847,17 @@ static int decode_impl(taco_ctx* c, const float* enc_out, int B, int T_in, int S
         c->dbg_stamps = reinterpret_cast<unsigned long long*>(pregion + pregion_floats);
         (void)hipMemsetAsync(sync, 0, 128, s);
         DecPersistArgs a{};
-        const DecW* W[11] = {&c->pre1, &c->pre2, &c->att_g, &c->att_c, &c->query, &c->proj,
-                             &c->g1_g, &c->g1_c, &c->g2_g, &c->g2_c, &c->outp};
+        const DecW* W[11] = {&c->pre1_f, &c->pre2, &c->att_g, &c->att_c, &c->query, &c->proj,
+                             &c->g1_g_f, &c->g1_c_f, &c->g2_g, &c->g2_c, &c->outp};
         for (int i = 0; i < 11; ++i) { a.Wp[i] = W[i]->Wp; a.bias[i] = W[i]->bias; }
+        a.bias_pre1_go = c->pre1.bias;
         a.attn_v = c->attn_v; a.keys = d.keys; a.values = enc_out;
         a.region = pregion; a.region_bytes = (unsigned)(pregion_floats * 4);
         size_t o = 0;
         auto takeg = [&](int dim) { const unsigned r = (unsigned)o; o += (size_t)dim * g1; return r; };
-        a.o_go = takeg(80); a.o_ctx = takeg(256); a.o_hatt = takeg(512); a.o_h1 = takeg(512); a.o_h2 = takeg(512);
+        a.o_hc = takeg(1024); a.o_h1 = takeg(512); a.o_h2 = takeg(512);
         a.o_p1 = takeg(256); a.o_p2 = takeg(128); a.o_rh = takeg(768); a.o_u = takeg(768); a.o_q = takeg(256);
-        a.o_d0 = takeg(256); a.o_o1 = takeg(256); a.o_o2 = takeg(256);
+        a.o_o1 = takeg(256); a.o_o2 = takeg(256);
         a.o_e = (unsigned)o; o += pe_floats;
         a.o_outQ = (unsigned)o;
         a.alignS = d.alignS; a.sync = sync; a.B = B; a.Bpad = Bp; a.T_in = T_in; a.S = S;
@@ -991,11 +1051,13 @@ extern "C" int taco_decode_status(taco_handle h) {
     HIP_OK(hipMemcpy(&w, h->sync_words, 8, hipMemcpyDeviceToHost));
 #ifdef PD_STAMPS
     if (h->dbg_stamps) {
-        unsigned long long st[64];
+        unsigned long long st[256];
         HIP_OK(hipMemcpy(st, h->dbg_stamps, sizeof(st), hipMemcpyDeviceToHost));
+        // flags: | stage boundary, r = a poll round of wave 0 done, m = MFMAs issued, e = reduced tile ready
         fprintf(stderr, "[pd stamps, 10 ns ticks since step start]");
-        for (int i = 1; i < 64 && st[i]; ++i)
-            fprintf(stderr, (st[i] >> 62) ? " (%llu)" : " %llu", (st[i] & ~(3ull << 62)) - st[0]);
+        const char* fl = "|rme";
+        for (int i = 1; i < 256 && st[i]; ++i)
+            fprintf(stderr, " %c%llu", fl[(st[i] >> 60) & 3], (st[i] & ~(15ull << 60)) - (st[0] & ~(15ull << 60)));
         fprintf(stderr, "\n");
     }
 #endif

@@ -2,27 +2,28 @@
 // model/helpers.py:66-78; step maths SURVEY.md A.7) as ONE launch for the default layer sizes
 // (prenet 256/128, attention/decoder depth 256, 80 mels x r=5, 256-wide encoder memory).
 //
-// Why: a decoder step is a chain of 13 dependent all-to-all stages with ~1 us of arithmetic each; as separate
+// Why: a decoder step is a chain of dependent all-to-all stages with ~0.5 us of arithmetic each; as separate
 // kernels every stage pays a dispatch boundary and re-streams its weights.  Here
-//   * each b-tile of 16 utterances is owned by a group of 32 workgroups (one per CU, 512 threads);
-//     workgroup j computes the same 16-row output tile j of every stage for all S steps, so its
-//     slices of ALL decoder weights (~316 KB) stay in registers for the whole decode: per step no weight
-//     byte moves (4 waves, one per SIMD, 70 dwordx4 per lane loaded once; VGPR+AGPR file of 512);
+//   * each b-tile of 16 utterances is owned by a group of 32 workgroups (one per CU, 256 threads = one wave per
+//     SIMD with the whole 512-entry register file); a workgroup computes the same 16-row output tile of its
+//     stages for all S steps, so its slices of the decoder weights (58 quads per lane) stay in registers for the
+//     whole decode: per step no weight byte moves;
 //   * the GRU state / residual tiles a workgroup owns stay in registers as well;
-//   * the encoder memory of an utterance is staged once into the LDS of the two workgroups that
-//     share its attention (keys: each half of T_in; values: each half of the 256 channels), when it fits
-//     (T_in <= 150 at the default sizes; otherwise it is read from L2);
-//   * stages hand activations over through a small global region in the decoder-step "Q layout"
-//     (decoder.hip) with write-through (sc1) 16-byte stores, every storing wave drains its stores
-//     (s_waitcnt vmcnt(0)), one lane per workgroup arrives on the group's monotonic counter with an
-//     agent-scope atomic add and polls it with sc1 loads; after the workgroup barrier that follows,
-//     every load of handed-off bytes is an sc1 buffer load (bypasses the CU's L1, which other CUs'
-//     stores never refresh).  Placement-independent; no reliance on dispatch order or XCD sharing.
-//   * every spin is bounded: on timeout the group's abort word is set, all waits fall through and
-//     the host reports the error.
+//   * the encoder memory of an utterance is staged once into the LDS of the two workgroups that share its
+//     attention (keys: each half of T_in; values: each half of the 256 channels), when it fits (T_in <= 150 at the
+//     default sizes; otherwise it is read from L2);
+//   * stages hand activations over as 8-byte {value, tag} granules (below): placement-independent, no reliance
+//     on dispatch order or XCD sharing;
+//   * two linear layers are folded into their consumers' weights at load time (api.hip Loader::dec_fold) and so
+//     leave the dependency chain: the r-frame output projection (next step's prenet-1 reads o2 directly; the
+//     frames themselves are computed one stage later, off the chain) and the concat projection (GRU-1 reads
+//     [h_att ; ctx] directly; d0, needed only for the residual, is computed locally by the workgroup that owns the
+//     matching GRU-1 tile). 11 hand-offs per step instead of 13;
+//   * every spin is bounded: on timeout the launch's abort word is set, all waits fall through and the host
+//     reports the error (taco_decode_status).
 // Reductions have a fixed order of their own (K split over 4 waves, two workgroups per utterance in the
 // attention): results are reproducible and batch-independent, and differ from the per-stage kernels
-// (decoder.hip, K over 8 waves) only by fp32 rounding.
+// (decoder.hip, K over 8 waves, unfolded weights) only by fp32 rounding.
 #include "kernels.h"
 #include "dec_common.h"
 
@@ -87,7 +88,10 @@ struct Spin {
     unsigned n;
     bool dead;
 #ifdef PD_STAMPS
-    unsigned long long* dbg; int stamp_i; bool stamp_on;
+    unsigned long long* st_lds; int stamp_i; bool stamp_on;    // diagnostic builds: stamps collected in LDS
+    __device__ __forceinline__ void stamp(unsigned long long flag) {
+        if (stamp_on && stamp_i < 250) st_lds[stamp_i++] = __builtin_amdgcn_s_memrealtime() | (flag << 60);
+    }
 #endif
     __device__ __forceinline__ bool give_up() {
         if (dead) return true;
@@ -109,10 +113,12 @@ struct Spin {
 // two more quads of its epilogue (update gate, residual) in the same poll loop of its first batch.
 // Returns the reduced tile fragment in wave 0 (lane: column b = lane&15, rows 4*(lane>>4)..+3).
 struct Extra { unsigned off, tag; f32x4 val; };
+// the K dimension of a stage is up to three consecutive segments of k16-steps, each its own granule buffer and tag
+struct Segs { unsigned off0, tag0; int e0; unsigned off1, tag1; int e1; unsigned off2, tag2; };
 template <int CH, int NX>
-__device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_rsrc_t rs, unsigned off0, unsigned tag0,
-                                        int k16_0, unsigned off1, unsigned tag1, int nk16, int Bpad, int lb, int lq,
-                                        int wave_v, int lane, f32x4* red, Spin& spin, Extra* ex) {
+__device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_rsrc_t rs, const Segs sg, int nk16,
+                                        int Bpad, int lb, int lq, int wave_v, int lane, f32x4* red, Spin& spin,
+                                        Extra* ex) {
     const int wave = __builtin_amdgcn_readfirstlane(wave_v);              // provably uniform -> scalar addressing
     const unsigned lane_bytes = (unsigned)(lq * Bpad + lb) * 32u;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -120,28 +126,53 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
     for (int h = 0; h < CH; h += PD_BATCH) {
         GQuad g[PD_BATCH];
         GQuad gx[NX > 0 ? NX : 1];
+        // a k16-step that has arrived is not fetched again: a retry only re-reads what is still missing
+        bool have[PD_BATCH], havex[NX > 0 ? NX : 1];
+#pragma unroll
+        for (int i = 0; i < PD_BATCH; ++i) have[i] = false;
+#pragma unroll
+        for (int i = 0; i < (NX > 0 ? NX : 1); ++i) havex[i] = false;
         while (true) {
             bool ok = true;
 #pragma unroll
             for (int i = 0; i < PD_BATCH; ++i) {
                 const int ks = wave * CH + h + i;
-                if (h + i < CH && ks < nk16) {
-                    const bool first = ks < k16_0;
-                    const unsigned uni = first ? (off0 + (unsigned)(4 * ks * Bpad) * 8u) * 4u
-                                               : (off1 + (unsigned)(4 * (ks - k16_0) * Bpad) * 8u) * 4u;
+                if (h + i < CH && ks < nk16 && !have[i]) {
+                    const int s = ks < sg.e0 ? 0 : (ks < sg.e1 ? 1 : 2);
+                    const unsigned off = s == 0 ? sg.off0 : (s == 1 ? sg.off1 : sg.off2);
+                    const int kb = s == 0 ? 0 : (s == 1 ? sg.e0 : sg.e1);
+                    const unsigned uni = (off + (unsigned)(4 * (ks - kb) * Bpad) * 8u) * 4u;
                     g[i] = pd_ldg2(rs, lane_bytes, uni);
-                    ok = ok && gq_ok(g[i], first ? tag0 : tag1);
                 }
             }
             if (NX > 0 && h == 0 && wave == 0) {
 #pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    gx[i] = pd_ldg(rs, ex[i].off);
-                    ok = ok && gq_ok(gx[i], ex[i].tag);
+                for (int i = 0; i < NX; ++i)
+                    if (!havex[i]) gx[i] = pd_ldg(rs, ex[i].off);
+            }
+#pragma unroll
+            for (int i = 0; i < PD_BATCH; ++i) {
+                const int ks = wave * CH + h + i;
+                if (h + i < CH && ks < nk16 && !have[i]) {
+                    const int s = ks < sg.e0 ? 0 : (ks < sg.e1 ? 1 : 2);
+                    const unsigned tag = s == 0 ? sg.tag0 : (s == 1 ? sg.tag1 : sg.tag2);
+                    have[i] = __all(gq_ok(g[i], tag));
+                    ok = ok && have[i];
                 }
             }
-            if (__all(ok) || spin.give_up()) break;
+            if (NX > 0 && h == 0 && wave == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+                    if (!havex[i]) {
+                        havex[i] = __all(gq_ok(gx[i], ex[i].tag));
+                        ok = ok && havex[i];
+                    }
+            }
+            if (ok || spin.give_up()) break;
         }
+#ifdef PD_STAMPS
+        if (wave_v == 0 && lane == 0) spin.stamp(1);
+#endif
         if (NX > 0 && h == 0 && wave == 0) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) ex[i].val = gq_val(gx[i]);
@@ -159,7 +190,7 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
         }
     }
 #ifdef PD_STAMPS
-    if (spin.stamp_on && wave_v == 0 && lane == 0 && spin.stamp_i < 60) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); spin.dbg[spin.stamp_i++] = __builtin_amdgcn_s_memrealtime() | (1ull << 62); }
+    if (wave_v == 0 && lane == 0) spin.stamp(2);
 #endif
     __syncthreads();                       // previous readers of `red` are done
     red[wave * 64 + lane] = acc0 + acc1;
@@ -170,6 +201,9 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
 #pragma unroll
         for (int ww = 1; ww < PD_WAVES; ++ww) v += red[ww * 64 + lane];
     }
+#ifdef PD_STAMPS
+    if (wave_v == 0 && lane == 0) spin.stamp(3);
+#endif
     return v;
 }
 
@@ -201,12 +235,17 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
 }
 
+template <int N, int CH>
+__device__ __forceinline__ float4 (&pd_sub(float4 (&w)[CH], int first))[N] {
+    return *reinterpret_cast<float4(*)[N]>(&w[first]);
+}
+
 __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS carve (all offsets multiples of 16)
     f32x4* red = reinterpret_cast<f32x4*>(smem);                         // [4][64] f32x4 (also ctx partials), 8 KB reserved
-    float* bias_s = reinterpret_cast<float*>(smem + 8192);               // [ST_COUNT][16]
-    float* e_s = bias_s + ST_COUNT * 16;                                 // (8 bias slots of 16 used)                                 // [T_in rounded to 4]
+    float* bias_s = reinterpret_cast<float*>(smem + 8192);               // [ST_COUNT][16] reserved, SL_COUNT slots used
+    float* e_s = bias_s + ST_COUNT * 16;                                 // [T_in rounded to 4]
     const int T4 = (a.T_in + 3) & ~3;
     float* keys_s = e_s + T4;                                            // [Th][256] when staged
     const int Th = (a.T_in + 1) >> 1;
@@ -219,44 +258,54 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.region, 0, a.region_bytes, 0x00020000);
     Spin spin{reinterpret_cast<unsigned*>(a.sync) + 1, 0u, false};
 #ifdef PD_STAMPS
-    spin.dbg = a.dbg; spin.stamp_i = 0; spin.stamp_on = false;
+    spin.st_lds = reinterpret_cast<unsigned long long*>(smem + 4096); spin.stamp_i = 0; spin.stamp_on = false;
 #endif
 
-    // ---- roles. The 32 workgroups of a group split the 16-tile stages between them so that each holds only 52
-    // weight quads per lane (208 registers) and the rest of the register file can keep a whole stage's operands in flight:
-    //   role A (j < 16, k = j): prenet-1 tile k, query tile k, concat-projection tile k (owns d0), GRU-1 owner
-    //        (reset-gate tile k, candidate tile k, owns h1 / o1), update-gate tiles of the attention GRU and of GRU-2,
-    //        output tiles 16..24 (k < 9);
+    // ---- roles. The 32 workgroups of a group split the stages between them so that each holds 58 weight quads per
+    // lane (232 registers) and the rest of the register file keeps a stage's operands in flight:
+    //   role A (j < 16, k = j): prenet-1 (folded: reads o2) tile k, GRU-1 owner (folded reset-gate tile k, local
+    //        concat-projection tile k for the residual, folded candidate tile k, owns h1 / o1), update-gate tiles of the
+    //        attention GRU and of GRU-2, output tiles 16..24 (k < 9);
     //   role B (j >= 16, k = j-16): prenet-2 tile k (k < 8), attention-GRU owner (reset tile k, candidate tile k, owns
-    //        h_att), GRU-2 owner (reset tile k, candidate tile k, owns h2), update-gate tiles of GRU-1, output tiles 0..15.
+    //        h_att), query tile k, GRU-2 owner (reset tile k, candidate tile k, owns h2), update-gate tiles of GRU-1
+    //        (folded), output tiles 0..15.
     const bool roleA = j < 16;
     const int k = roleA ? j : j - 16;
-    enum { SL_GATT = 0, SL_G1, SL_G2, SL_X6, SL_X8A, SL_X8B, SL_X4A, SL_X4B, SL_COUNT };
-    float4 wg_att[6], wg_1[8], wg_2[8], wx6[6], wx8a[8], wx8b[8], wx4a[4], wx4b[4];
-    const int t_gatt = roleA ? 16 + k : k, t_g1 = roleA ? k : 16 + k, t_g2 = roleA ? 16 + k : k;
+    enum { SL_A6 = 0, SL_G12, SL_G8, SL_X8A, SL_X8B0, SL_X8B1, SL_X12, SL_O4, SL_GO, SL_COUNT };
+    float4 a6[6], g12[12], g8[8], x8a[8], x8b[8], x12[12], o4[4];
+    const int t_a6 = roleA ? 16 + k : k, t_g12 = roleA ? k : 16 + k, t_g8 = roleA ? 16 + k : k;
     const int t_out = roleA ? 16 + k : k;
-    pd_load_w<6>(wg_att, a.Wp[ST_ATTG], t_gatt, 32, 24, wave, lane);
-    pd_load_w<8>(wg_1, a.Wp[ST_G1G], t_g1, 32, 32, wave, lane);
-    pd_load_w<8>(wg_2, a.Wp[ST_G2G], t_g2, 32, 32, wave, lane);
-    pd_load_w<6>(wx6, a.Wp[roleA ? ST_PRE1 : ST_ATTC], k, 16, 24 - (roleA ? 3 : 0), wave, lane);
-    pd_load_w<8>(wx8a, a.Wp[roleA ? ST_PROJ : ST_G2C], k, 16, 32, wave, lane);
-    pd_load_w<8>(wx8b, a.Wp[ST_G1C], k, roleA ? 16 : 0, 32, wave, lane);
-    pd_load_w<4>(wx4a, a.Wp[roleA ? ST_QUERY : ST_PRE2], k, roleA ? 16 : 8, 16, wave, lane);
-    pd_load_w<4>(wx4b, a.Wp[ST_OUT], t_out, 25, 16, wave, lane);
+    pd_load_w<6>(a6, a.Wp[ST_ATTG], t_a6, 32, 24, wave, lane);
+    pd_load_w<12>(g12, a.Wp[ST_G1G], t_g12, 32, 48, wave, lane);
+    pd_load_w<8>(g8, a.Wp[ST_G2G], t_g8, 32, 32, wave, lane);
+    pd_load_w<8>(x8a, a.Wp[roleA ? ST_PRE1 : ST_G2C], k, 16, 32, wave, lane);
+    if (roleA) {
+        pd_load_w<8>(x8b, a.Wp[ST_PROJ], k, 16, 32, wave, lane);
+        pd_load_w<12>(x12, a.Wp[ST_G1C], k, 16, 48, wave, lane);
+    } else {
+        pd_load_w<4>(pd_sub<4>(x8b, 0), a.Wp[ST_QUERY], k, 16, 16, wave, lane);
+        pd_load_w<4>(pd_sub<4>(x8b, 4), a.Wp[ST_PRE2], k, 8, 16, wave, lane);
+        pd_load_w<6>(pd_sub<6>(x12, 0), a.Wp[ST_ATTC], k, 16, 24, wave, lane);
+#pragma unroll
+        for (int i = 6; i < 12; ++i) x12[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    pd_load_w<4>(o4, a.Wp[ST_OUT], t_out, 25, 16, wave, lane);
     for (int i = tid; i < SL_COUNT * 16; i += PD_THREADS) {
         const int sl = i >> 4, r = i & 15;
-        int st, tile, nt;
+        const float* bp = nullptr;
+        int tile = k, nt = 16;
         switch (sl) {
-            case SL_GATT: st = ST_ATTG; tile = t_gatt; nt = 32; break;
-            case SL_G1: st = ST_G1G; tile = t_g1; nt = 32; break;
-            case SL_G2: st = ST_G2G; tile = t_g2; nt = 32; break;
-            case SL_X6: st = roleA ? ST_PRE1 : ST_ATTC; tile = k; nt = 16; break;
-            case SL_X8A: st = roleA ? ST_PROJ : ST_G2C; tile = k; nt = 16; break;
-            case SL_X8B: st = ST_G1C; tile = k; nt = roleA ? 16 : 0; break;
-            case SL_X4A: st = roleA ? ST_QUERY : ST_PRE2; tile = k; nt = roleA ? 16 : 8; break;
-            default: st = ST_OUT; tile = t_out; nt = 25; break;
+            case SL_A6: bp = a.bias[ST_ATTG]; tile = t_a6; nt = 32; break;
+            case SL_G12: bp = a.bias[ST_G1G]; tile = t_g12; nt = 32; break;
+            case SL_G8: bp = a.bias[ST_G2G]; tile = t_g8; nt = 32; break;
+            case SL_X8A: bp = a.bias[roleA ? ST_PRE1 : ST_G2C]; break;
+            case SL_X8B0: bp = roleA ? a.bias[ST_PROJ] : nullptr; break;
+            case SL_X8B1: bp = roleA ? nullptr : a.bias[ST_PRE2]; nt = 8; break;
+            case SL_X12: bp = a.bias[roleA ? ST_G1C : ST_ATTC]; break;
+            case SL_O4: bp = a.bias[ST_OUT]; tile = t_out; nt = 25; break;
+            default: bp = roleA ? a.bias_pre1_go : nullptr; break;
         }
-        bias_s[i] = (a.bias[st] && tile < nt) ? a.bias[st][tile * 16 + r] : 0.f;
+        bias_s[i] = (bp && tile < nt) ? bp[tile * 16 + r] : 0.f;
     }
     // ---- attention role: utterance u of the group, half `hf` (keys: half of T_in; values: half of the channels)
     const int u_loc = j >> 1, hf = j & 1;
@@ -283,35 +332,53 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
     const unsigned te16 = (unsigned)(((16 + k) * 4 + lq) * Bpad + lb) * 8u; // ... in tile 16+k (output frames)
     const unsigned st_stride = (unsigned)(256 * Bpad * 2);                   // one 256-wide granule buffer
 #ifdef PD_STAMPS
-#define PD_STAMP() do { spin.stamp_on = (blockIdx.x == PD_STAMP_WG && s == 5); if (spin.stamp_on && tid == 0 && spin.stamp_i < 60) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); a.dbg[spin.stamp_i++] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define PD_STAMP() do { spin.stamp_on = (blockIdx.x == PD_STAMP_WG && s == 5); if (tid == 0) spin.stamp(0); } while (0)
 #else
 #define PD_STAMP() do {} while (0)
 #endif
 #define PD_BIAS(sl) (*reinterpret_cast<const f32x4*>(bias_s + (sl) * 16 + 4 * lq))
-#define PD_MMA(CH, NX, W, o0, t0, k0, o1, t1, nk, EX) \
-    pd_mma<CH, NX>(W, rs, o0, t0, k0, o1, t1, nk, Bpad, lb, lq, wave, lane, red, spin, EX)
+#define PD_MMA(CH, NX, W, SG, nk, EX) pd_mma<CH, NX>(W, rs, SG, nk, Bpad, lb, lq, wave, lane, red, spin, EX)
+    // the r output frames of step `so` (decoder.py:35) from o2, which must carry tag `to2`
+#define PD_OUT(so, to2)                                                                                              \
+    do {                                                                                                             \
+        if (!roleA || k < 9) {                                                                                       \
+            const Segs sgo{a.o_o2, (to2), 16, 0u, 0u, 16, 0u, 0u};                                                   \
+            f32x4 v = PD_MMA(4, 0, o4, sgo, 16, ex);                                                                 \
+            if (wave == 0)                                                                                           \
+                pd_stg(rs, a.o_outQ + (unsigned)((so) * 400) * Bpad * 2u + (roleA ? te16 : te), v + PD_BIAS(SL_O4),  \
+                       (to2) + 1u);                                                                                  \
+        }                                                                                                            \
+    } while (0)
 
     for (int s = 0; s < a.S; ++s) {
         const unsigned T = (unsigned)(PD_STAGES * s);                 // tag of stage i of this step = T + i + 1
         const unsigned Tp = s ? T - PD_STAGES : 0u;                   // previous step (tags below are 0 at s == 0)
         const unsigned cur = (unsigned)(s & 1) * st_stride, prv = (unsigned)((s & 1) ^ 1) * st_stride;
-        const unsigned o_prev = s == 0 ? a.o_go : a.o_outQ + (unsigned)((s - 1) * 400 + 320) * Bpad * 2u;
+        // [h_att ; ctx] of a step are one 512-wide buffer, double-buffered by step parity
+        const unsigned hc = a.o_hc + (unsigned)(s & 1) * 2u * st_stride, hcp = a.o_hc + (unsigned)((s & 1) ^ 1) * 2u * st_stride;
+        const unsigned o_ctx = hc + st_stride, o_ctxp = hcp + st_stride;
         Extra ex[2];
         PD_STAMP();
-        // ---- stage 0/1: decoder prenet (rnn_wrappers.py:25): relu(W1 [prev; ctx] + b1), relu(W2 . + b2)
+        // ---- stage 0/1: decoder prenet (rnn_wrappers.py:25): relu(W1 [prev frame; ctx] + b1) with the output projection
+        // folded in (prev frame = last of the r frames of o2), relu(W2 . + b2); step 0 feeds the <GO> frame: o2 = 0, own bias
         if (roleA) {
-            f32x4 v = PD_MMA(6, 0, wx6, o_prev, s ? Tp + 13u : 0u, 5, a.o_ctx, s ? Tp + 7u : 0u, 21, ex);
-            if (wave == 0) pd_stg(rs, a.o_p1 + te, relu4(v + PD_BIAS(SL_X6)), T + 1u);
-        } else if (k < 8) {
-            f32x4 v = PD_MMA(4, 0, wx4a, a.o_p1, T + 1u, 16, 0u, 0u, 16, ex);
-            if (wave == 0) pd_stg(rs, a.o_p2 + te, relu4(v + PD_BIAS(SL_X4A)), T + 2u);
+            const Segs sg{a.o_o2, s ? Tp + 12u : 0u, 16, o_ctxp, s ? Tp + 7u : 0u, 32, 0u, 0u};
+            f32x4 v = PD_MMA(8, 0, x8a, sg, 32, ex);
+            if (wave == 0) pd_stg(rs, a.o_p1 + te, relu4(v + PD_BIAS(s ? SL_X8A : SL_GO)), T + 1u);
+        }
+        if (s) PD_OUT(s - 1, Tp + 12u);       // previous step's frames: off the dependency chain
+        if (!roleA && k < 8) {
+            const Segs sg{a.o_p1, T + 1u, 16, 0u, 0u, 16, 0u, 0u};
+            f32x4 v = PD_MMA(4, 0, pd_sub<4>(x8b, 4), sg, 16, ex);
+            if (wave == 0) pd_stg(rs, a.o_p2 + te, relu4(v + PD_BIAS(SL_X8B1)), T + 2u);
         }
         PD_STAMP();
         // ---- stage 2/3: attention GRU (rnn_wrappers.py:26): gates (A: update tile, B: reset tile), candidate (B)
         {
-            f32x4 v = PD_MMA(6, 0, wg_att, a.o_p2, T + 2u, 8, a.o_hatt + prv, s ? Tp + 4u : 0u, 24, ex);
+            const Segs sg{a.o_p2, T + 2u, 8, hcp, s ? Tp + 4u : 0u, 24, 0u, 0u};
+            f32x4 v = PD_MMA(6, 0, a6, sg, 24, ex);
             if (wave == 0) {
-                const f32x4 g = sig4(v + PD_BIAS(SL_GATT));
+                const f32x4 g = sig4(v + PD_BIAS(SL_A6));
                 if (roleA) pd_stg(rs, a.o_u + te, g, T + 3u);
                 else pd_stg(rs, a.o_rh + te, g * hA_t, T + 3u);
             }
@@ -319,39 +386,38 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
         PD_STAMP();
         if (!roleA) {
             ex[0].off = a.o_u + te; ex[0].tag = T + 3u;
-            f32x4 v = PD_MMA(6, 1, wx6, a.o_p2, T + 2u, 8, a.o_rh, T + 3u, 24, ex);
+            const Segs sg{a.o_p2, T + 2u, 8, a.o_rh, T + 3u, 24, 0u, 0u};
+            f32x4 v = PD_MMA(6, 1, pd_sub<6>(x12, 0), sg, 24, ex);
             if (wave == 0) {
                 const f32x4 ug = ex[0].val;
-                const f32x4 c = tanh4(v + PD_BIAS(SL_X6));
+                const f32x4 c = tanh4(v + PD_BIAS(SL_X12));
                 hA_t = ug * hA_t + (1.f - ug) * c;
-                pd_stg(rs, a.o_hatt + cur + te, hA_t, T + 4u);
+                pd_stg(rs, hc + te, hA_t, T + 4u);
             }
-        }
-        PD_STAMP();
-        // ---- stage 4..6: Bahdanau attention (decoder.py:20): query (A), scores, softmax, context (all)
-        if (roleA) {
-            f32x4 v = PD_MMA(4, 0, wx4a, a.o_hatt + cur, T + 4u, 16, 0u, 0u, 16, ex);
+            PD_STAMP();
+            // ---- stage 4: attention query (decoder.py:20)
+            const Segs sq{hc, T + 4u, 16, 0u, 0u, 16, 0u, 0u};
+            v = PD_MMA(4, 0, pd_sub<4>(x8b, 0), sq, 16, ex);
             if (wave == 0) pd_stg(rs, a.o_q + te, v, T + 5u);
         }
         PD_STAMP();
+        // ---- stage 5/6: Bahdanau scores, softmax, context (all workgroups)
         if (!att_on) {
             // padded column of the last 16-utterance tile: no attention, but its context quads must still carry this
             // step's tag for the stages that read whole tiles (ordered after q, like the real ones)
             (void)pd_wait_quad(rs, a.o_q + (unsigned)(lane * Bpad + b_att) * 8u, T + 5u, spin);
             if (tid < 32)
-                pd_stg(rs, a.o_ctx + (unsigned)((hf * 32 + tid) * Bpad + b_att) * 8u, f32x4{0.f, 0.f, 0.f, 0.f}, T + 7u);
+                pd_stg(rs, o_ctx + (unsigned)((hf * 32 + tid) * Bpad + b_att) * 8u, f32x4{0.f, 0.f, 0.f, 0.f}, T + 7u);
         }
         if (att_on) {
             // scores of this half: e_t = sum_d v_d tanh(keys[t,d] + q_d); lane owns dims 4*lane..+3, wave owns t
             const f32x4 qq = pd_wait_quad(rs, a.o_q + (unsigned)(lane * Bpad + b_att) * 8u, T + 5u, spin);
-            for (int t = wave; t < t_n; t += 2 * PD_WAVES) {
-                const int t1 = t + PD_WAVES;
-                const float4 k0 = a.lds_keys ? reinterpret_cast<const float4*>(keys_s)[t * 64 + lane]
-                                             : reinterpret_cast<const float4*>(keys_g)[t * 64 + lane];
-                float4 k1 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t1 < t_n)
-                    k1 = a.lds_keys ? reinterpret_cast<const float4*>(keys_s)[t1 * 64 + lane]
-                                    : reinterpret_cast<const float4*>(keys_g)[t1 * 64 + lane];
+#ifdef PD_STAMPS
+            if (tid == 0) spin.stamp(1);
+#endif
+            // (separate LDS / global loops: one loop over a selected pointer becomes flat loads, whose waits also
+            // cover the sc1 stores in flight)
+            auto score2 = [&](const float4 k0, const float4 k1, int t, int t1) {
                 float s0 = v_att.x * fast_tanh(k0.x + qq.x) + v_att.y * fast_tanh(k0.y + qq.y) +
                            v_att.z * fast_tanh(k0.z + qq.z) + v_att.w * fast_tanh(k0.w + qq.w);
                 float s1 = v_att.x * fast_tanh(k1.x + qq.x) + v_att.y * fast_tanh(k1.y + qq.y) +
@@ -359,25 +425,42 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
                 s0 = wave_sum(s0);
                 s1 = wave_sum(s1);
                 if (lane == 0) {
-                    const unsigned eo = a.o_e + (unsigned)(b_att * a.T_in + t_lo + t) * 2u;
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(s0), T + 6u}, rs, eo * 4u, 0, 16);
-                    if (t1 < t_n)
-                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(s1), T + 6u}, rs,
-                                                              (eo + 2u * PD_WAVES) * 4u, 0, 16);
+                    e_s[t_lo + t] = s0;
+                    if (t1 < t_n) e_s[t_lo + t1] = s1;
+                }
+            };
+            __syncthreads();                       // e_s free (previous step's context done)
+            if (a.lds_keys) {
+                const float4* kp = reinterpret_cast<const float4*>(keys_s);
+                for (int t = wave; t < t_n; t += 2 * PD_WAVES) {
+                    const int t1 = t + PD_WAVES;
+                    score2(kp[t * 64 + lane], kp[(t1 < t_n ? t1 : t) * 64 + lane], t, t1);
+                }
+            } else {
+                const float4* kp = reinterpret_cast<const float4*>(keys_g);
+                for (int t = wave; t < t_n; t += 2 * PD_WAVES) {
+                    const int t1 = t + PD_WAVES;
+                    score2(kp[t * 64 + lane], kp[(t1 < t_n ? t1 : t) * 64 + lane], t, t1);
                 }
             }
+            __syncthreads();
+            // publish this half's scores as {e, tag} granules (one coalesced store), fetch the other half's
+            for (int t = tid; t < t_n; t += PD_THREADS)
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(e_s[t_lo + t]), T + 6u}, rs,
+                                                      (a.o_e + (unsigned)(b_att * a.T_in + t_lo + t) * 2u) * 4u, 0, 16);
             PD_STAMP();
-            // all T_in scores (both halves) -> LDS
-            __syncthreads();                       // e_s free (previous step's context done)
-            for (int t0 = 0; t0 < a.T_in; t0 += PD_THREADS) {
-                const int t = t0 + tid;
-                u32x2 g = {0u, T + 6u};
-                while (true) {
-                    if (t < a.T_in)
-                        g = __builtin_amdgcn_raw_buffer_load_b64(rs, (a.o_e + (unsigned)(b_att * a.T_in + t) * 2u) * 4u, 0, 16);
-                    if (__all(g.y == T + 6u) || spin.give_up()) break;
+            {
+                const int o_lo = hf ? 0 : Th, o_n = a.T_in - t_n;
+                for (int t0 = 0; t0 < o_n; t0 += PD_THREADS) {
+                    const int t = t0 + tid;
+                    u32x2 g = {0u, T + 6u};
+                    while (true) {
+                        if (t < o_n)
+                            g = __builtin_amdgcn_raw_buffer_load_b64(rs, (a.o_e + (unsigned)(b_att * a.T_in + o_lo + t) * 2u) * 4u, 0, 16);
+                        if (__all(g.y == T + 6u) || spin.give_up()) break;
+                    }
+                    if (t < o_n) e_s[o_lo + t] = __uint_as_float(g.x);
                 }
-                if (t < a.T_in) e_s[t] = __uint_as_float(g.x);
             }
             __syncthreads();
             PD_STAMP();
@@ -405,12 +488,21 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
             // context, this half's 128 channels: lane = (t parity, channel quad), waves stride t by 8
             const int dq = lane & 31, tp = lane >> 5;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int t = 2 * wave + tp; t < a.T_in; t += 2 * PD_WAVES) {
-                const float4 x = a.lds_vals ? reinterpret_cast<const float4*>(vals_s)[t * 32 + dq]
-                                            : reinterpret_cast<const float4*>(vals_g + (size_t)t * 256)[dq];
-                const float p = e_s[t];
-                acc.x = fmaf(p, x.x, acc.x); acc.y = fmaf(p, x.y, acc.y);
-                acc.z = fmaf(p, x.z, acc.z); acc.w = fmaf(p, x.w, acc.w);
+            if (a.lds_vals) {
+                const float4* vp = reinterpret_cast<const float4*>(vals_s);
+                for (int t = 2 * wave + tp; t < a.T_in; t += 2 * PD_WAVES) {
+                    const float4 x = vp[t * 32 + dq];
+                    const float p = e_s[t];
+                    acc.x = fmaf(p, x.x, acc.x); acc.y = fmaf(p, x.y, acc.y);
+                    acc.z = fmaf(p, x.z, acc.z); acc.w = fmaf(p, x.w, acc.w);
+                }
+            } else {
+                for (int t = 2 * wave + tp; t < a.T_in; t += 2 * PD_WAVES) {
+                    const float4 x = reinterpret_cast<const float4*>(vals_g + (size_t)t * 256)[dq];
+                    const float p = e_s[t];
+                    acc.x = fmaf(p, x.x, acc.x); acc.y = fmaf(p, x.y, acc.y);
+                    acc.z = fmaf(p, x.z, acc.z); acc.w = fmaf(p, x.w, acc.w);
+                }
             }
             red[wave * 64 + lane] = acc;
             __syncthreads();
@@ -418,35 +510,34 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
                 f32x4 c = red[tid] + red[32 + tid];
 #pragma unroll
                 for (int ww = 1; ww < PD_WAVES; ++ww) c += red[ww * 64 + tid] + red[ww * 64 + 32 + tid];
-                pd_stg(rs, a.o_ctx + (unsigned)((hf * 32 + tid) * Bpad + b_att) * 8u, c, T + 7u);
+                pd_stg(rs, o_ctx + (unsigned)((hf * 32 + tid) * Bpad + b_att) * 8u, c, T + 7u);
             }
             PD_STAMP();
         }
-        // ---- stage 7: concat([h_att, ctx]) -> decoder depth (rnn_wrappers.py:53, decoder.py:29)  (A, owns d0)
-        if (roleA) {
-            f32x4 v = PD_MMA(8, 0, wx8a, a.o_hatt + cur, T + 4u, 16, a.o_ctx, T + 7u, 32, ex);
-            if (wave == 0) {
-                d0_t = v + PD_BIAS(SL_X8A);
-                pd_stg(rs, a.o_d0 + te, d0_t, T + 8u);
-            }
-        }
-        PD_STAMP();
-        // ---- stage 8/9: residual GRU 1 (decoder.py:30): gates (A: reset tile, B: update tile), candidate (A)
+        // ---- stage 8/9: residual GRU 1 (decoder.py:30) with the concat projection (rnn_wrappers.py:53, decoder.py:29)
+        // folded in: gates (A: reset tile, B: update tile) and candidate (A) read [h_att ; ctx ; h1] / [h_att ; ctx ; r.h1]
         {
-            f32x4 v = PD_MMA(8, 0, wg_1, a.o_d0, T + 8u, 16, a.o_h1 + prv, s ? Tp + 10u : 0u, 32, ex);
+            const Segs sg{hc, T + 4u, 16, o_ctx, T + 7u, 32, a.o_h1 + prv, s ? Tp + 10u : 0u};
+            f32x4 v = PD_MMA(12, 0, g12, sg, 48, ex);
             if (wave == 0) {
-                const f32x4 g = sig4(v + PD_BIAS(SL_G1));
+                const f32x4 g = sig4(v + PD_BIAS(SL_G12));
                 if (roleA) pd_stg(rs, a.o_rh + st_stride + te, g * hA_t, T + 9u);
                 else pd_stg(rs, a.o_u + st_stride + te, g, T + 9u);
             }
         }
         PD_STAMP();
         if (roleA) {
+            // d0 = W_p [h_att ; ctx] + b_p is only needed for the residual o1 = h1 + d0: computed here, by the
+            // workgroup that consumes it, while the reset gates of the other workgroups arrive
+            const Segs sp{hc, T + 4u, 16, o_ctx, T + 7u, 32, 0u, 0u};
+            f32x4 v = PD_MMA(8, 0, x8b, sp, 32, ex);
+            if (wave == 0) d0_t = v + PD_BIAS(SL_X8B0);
             ex[0].off = a.o_u + st_stride + te; ex[0].tag = T + 9u;
-            f32x4 v = PD_MMA(8, 1, wx8b, a.o_d0, T + 8u, 16, a.o_rh + st_stride, T + 9u, 32, ex);
+            const Segs sg{hc, T + 4u, 16, o_ctx, T + 7u, 32, a.o_rh + st_stride, T + 9u};
+            v = PD_MMA(12, 1, x12, sg, 48, ex);
             if (wave == 0) {
                 const f32x4 ug = ex[0].val;
-                const f32x4 c = tanh4(v + PD_BIAS(SL_X8B));
+                const f32x4 c = tanh4(v + PD_BIAS(SL_X12));
                 hA_t = ug * hA_t + (1.f - ug) * c;
                 o1_t = hA_t + d0_t;
                 pd_stg(rs, a.o_h1 + cur + te, hA_t, T + 10u);
@@ -456,9 +547,10 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
         PD_STAMP();
         // ---- stage 10/11: residual GRU 2 (decoder.py:31): gates (A: update tile, B: reset tile), candidate (B)
         {
-            f32x4 v = PD_MMA(8, 0, wg_2, a.o_o1, T + 10u, 16, a.o_h2 + prv, s ? Tp + 12u : 0u, 32, ex);
+            const Segs sg{a.o_o1, T + 10u, 16, a.o_h2 + prv, s ? Tp + 12u : 0u, 32, 0u, 0u};
+            f32x4 v = PD_MMA(8, 0, g8, sg, 32, ex);
             if (wave == 0) {
-                const f32x4 g = sig4(v + PD_BIAS(SL_G2));
+                const f32x4 g = sig4(v + PD_BIAS(SL_G8));
                 if (roleA) pd_stg(rs, a.o_u + 2u * st_stride + te, g, T + 11u);
                 else pd_stg(rs, a.o_rh + 2u * st_stride + te, g * hB_t, T + 11u);
             }
@@ -467,7 +559,8 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
         if (!roleA) {
             ex[0].off = a.o_u + 2u * st_stride + te; ex[0].tag = T + 11u;
             ex[1].off = a.o_o1 + te; ex[1].tag = T + 10u;
-            f32x4 v = PD_MMA(8, 2, wx8a, a.o_o1, T + 10u, 16, a.o_rh + 2u * st_stride, T + 11u, 32, ex);
+            const Segs sg{a.o_o1, T + 10u, 16, a.o_rh + 2u * st_stride, T + 11u, 32, 0u, 0u};
+            f32x4 v = PD_MMA(8, 2, x8a, sg, 32, ex);
             if (wave == 0) {
                 const f32x4 ug = ex[0].val;
                 const f32x4 c = tanh4(v + PD_BIAS(SL_X8A));
@@ -477,14 +570,17 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
             }
         }
         PD_STAMP();
-        // ---- stage 12: r output frames (decoder.py:35); the next step reads its last frame back (helpers.py:77)
-        if (!roleA || k < 9) {
-            f32x4 v = PD_MMA(4, 0, wx4b, a.o_o2, T + 12u, 16, 0u, 0u, 16, ex);
-            if (wave == 0)
-                pd_stg(rs, a.o_outQ + (unsigned)(s * 400) * Bpad * 2u + (roleA ? te16 : te), v + PD_BIAS(SL_X4B), T + 13u);
-        }
-        PD_STAMP();
+#ifdef PD_STAMPS
+        if (spin.stamp_on && tid == 0)
+            for (int i = 0; i < spin.stamp_i; ++i) a.dbg[i] = spin.st_lds[i];
+        spin.stamp_on = false;
+#endif
     }
+    {
+        Extra ex[2];
+        PD_OUT(a.S - 1, (unsigned)(PD_STAGES * (a.S - 1)) + 12u);
+    }
+#undef PD_OUT
 #undef PD_MMA
 #undef PD_BIAS
 }

@@ -115,17 +115,19 @@ void launch_dec_finalize(const float* outQ, int gran, const float* alignS, int32
 
 // Persistent decoder (dec_persistent.hip), default layer sizes only. Offsets o_* are in floats from `region`,
 // the contiguous, zero-filled block of granule buffers the workgroups exchange through (sc1 stores / loads):
-// a vector of dimension K takes K*Bpad*2 floats; hatt/h1/h2 are double-buffered by step parity (2 x 256 wide),
+// a vector of dimension K takes K*Bpad*2 floats; [h_att ; ctx] (512 wide), h1 and h2 are double-buffered by step parity,
 // rh and u hold one 256-wide buffer per GRU (3 each), e holds B*T_in {score, tag} pairs, outQ S*400 wide.
 struct DecPersistArgs {
-    const float* Wp[11];      // packed weights per stage: pre1, pre2, attG, attC, query, proj, g1G, g1C, g2G, g2C, out
+    const float* Wp[11];      // packed weights per stage: pre1 (folded, K = 512), pre2, attG, attC, query, proj,
+                              //   g1G, g1C (folded, K = 768), g2G, g2C, out
     const float* bias[11];    // or null
+    const float* bias_pre1_go;  // prenet-1 bias of step 0 (<GO> frame: no folded output-projection bias)
     const float* attn_v;
     const float* keys;        // [B, T_in, 256]
     const float* values;      // [B, T_in, 256] (encoder outputs)
     float* region;
     unsigned region_bytes;
-    unsigned o_go, o_ctx, o_hatt, o_h1, o_h2, o_p1, o_p2, o_rh, o_u, o_q, o_d0, o_o1, o_o2, o_e, o_outQ;
+    unsigned o_hc, o_h1, o_h2, o_p1, o_p2, o_rh, o_u, o_q, o_o1, o_o2, o_e, o_outQ;   // o_hc: 2 x [h_att ; ctx]
     float* alignS;            // [S][B][T_in]
     unsigned long long* sync; // {unused, abort word}, zeroed per call
     int B, Bpad, T_in, S;
