@@ -346,6 +346,8 @@ struct Loader {
     }
 };
 
+constexpr int PD_REGION_DIMS = 1024 + 512 + 512 + 256 + 128 + 768 + 768 + 256 + 256 + 256 + 256;   // 4992
+
 struct Carver {
     char* base; size_t off = 0, cap;
     Carver(void* p, size_t n) : base((char*)p), cap(n) {}
@@ -388,7 +390,7 @@ size_t dec_ws_bytes(const taco_ctx* c, int B, int T_in, int S) {
     n += al((size_t)S * NR * Bp * 4);                                        // outQ
     n += al((size_t)S * B * T_in * 4);                                       // alignS
     n += al((size_t)S * Bp * 4);                                             // nz
-    n += al(((size_t)4816 * Bp * 2 + 4096 + (size_t)B * T_in * 2 + 64 + (size_t)S * 400 * Bp * 2) * 4) + 4096;  // persistent decoder region
+    n += al(((size_t)PD_REGION_DIMS * Bp * 2 + 4096 + (size_t)B * T_in * 2 + 64 + (size_t)S * 400 * Bp * 2) * 4) + 4096;  // persistent decoder region
     const size_t state = (size_t)(hp.num_mels + Dv + hp.attention_depth + 2 * hp.decoder_depth) * Bp * 4;
     n += al(state);
     const int mx = std::max(hp.attention_depth, hp.decoder_depth);
@@ -833,8 +835,8 @@ static int decode_impl(taco_ctx* c, const float* enc_out, int B, int T_in, int S
                                hp.num_mels == 80 && hp.outputs_per_step == 5 && Dv == 256;
     const size_t g1 = (size_t)Bp * 2;                        // floats per unit of vector dimension, granule layout
     const size_t pe_floats = (((size_t)B * T_in * 2) + 63) & ~(size_t)63;
-    const size_t pregion_floats = (size_t)(80 + 256 + 6 * 256 + 256 + 128 + 3 * 256 + 3 * 256 + 4 * 256) * g1 + pe_floats +
-                                  (size_t)S * 400 * g1;
+    // granule buffers of dec_persistent.hip: [h_att;ctx] x2, h1 x2, h2 x2, p1, p2, rh x3, u x3, q, d0, o1, o2
+    const size_t pregion_floats = (size_t)PD_REGION_DIMS * g1 + pe_floats + (size_t)S * 400 * g1;
     if (c->decode_mode == 2 && default_sizes && !keep && !fine_timing && Bp / 16 <= 8 &&
         pregion_floats * 4 < (size_t)1 << 31) {
         float* pregion = ws.take<float>(pregion_floats + 1024);   // + 4 KB tail for diagnostic stamps (PD_STAMPS builds)
@@ -857,7 +859,8 @@ static int decode_impl(taco_ctx* c, const float* enc_out, int B, int T_in, int S
         auto takeg = [&](int dim) { const unsigned r = (unsigned)o; o += (size_t)dim * g1; return r; };
         a.o_hc = takeg(1024); a.o_h1 = takeg(512); a.o_h2 = takeg(512);
         a.o_p1 = takeg(256); a.o_p2 = takeg(128); a.o_rh = takeg(768); a.o_u = takeg(768); a.o_q = takeg(256);
-        a.o_o1 = takeg(256); a.o_o2 = takeg(256);
+        a.o_d0 = takeg(256); a.o_o1 = takeg(256); a.o_o2 = takeg(256);
+        if (o != (size_t)PD_REGION_DIMS * g1) return fail("taco_decode: persistent region layout mismatch");
         a.o_e = (unsigned)o; o += pe_floats;
         a.o_outQ = (unsigned)o;
         a.alignS = d.alignS; a.sync = sync; a.B = B; a.Bpad = Bp; a.T_in = T_in; a.S = S;

@@ -229,8 +229,15 @@ __device__ __forceinline__ void pd_load_w(float4 (&w)[CH], const float* Wp, int 
     }
 }
 
-__device__ __forceinline__ f32x4 sig4(f32x4 v) { return f32x4{dsigmoid(v.x), dsigmoid(v.y), dsigmoid(v.z), dsigmoid(v.w)}; }
-__device__ __forceinline__ f32x4 tanh4(f32x4 v) { return f32x4{dtanh(v.x), dtanh(v.y), dtanh(v.z), dtanh(v.w)}; }
+// gate non-linearities on the hardware exp2 / rcp (absolute error ~2e-7, like fast_tanh): the epilogue sits on the
+// step's dependency chain, the library expf + IEEE divide are ~4x the instructions
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+__device__ __forceinline__ f32x4 sig4(f32x4 v) {
+    return f32x4{fast_sigmoid(v.x), fast_sigmoid(v.y), fast_sigmoid(v.z), fast_sigmoid(v.w)};
+}
+__device__ __forceinline__ f32x4 tanh4(f32x4 v) { return f32x4{fast_tanh(v.x), fast_tanh(v.y), fast_tanh(v.z), fast_tanh(v.w)}; }
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
 }
@@ -245,9 +252,11 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
     // LDS carve (all offsets multiples of 16)
     f32x4* red = reinterpret_cast<f32x4*>(smem);                         // [4][64] f32x4 (also ctx partials), 8 KB reserved
     float* bias_s = reinterpret_cast<float*>(smem + 8192);               // [ST_COUNT][16] reserved, SL_COUNT slots used
-    float* e_s = bias_s + ST_COUNT * 16;                                 // [T_in rounded to 4]
+    float* e_s = bias_s + ST_COUNT * 16;                                 // [T_in rounded to 4] scores
     const int T4 = (a.T_in + 3) & ~3;
-    float* keys_s = e_s + T4;                                            // [Th][256] when staged
+    float* p_s = e_s + T4;                                               // [T_in rounded to 4] exp(score - max)
+    float* wsum_s = p_s + T4;                                            // [4] per-wave partial sums, [4..7] key range flags
+    float* keys_s = wsum_s + 8;                                          // [Th][256] when staged
     const int Th = (a.T_in + 1) >> 1;
     float* vals_s = keys_s + (a.lds_keys ? Th * 256 : 0);                // [T_in][128] when staged
 
@@ -263,12 +272,12 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
 
     // ---- roles. The 32 workgroups of a group split the stages between them so that each holds 58 weight quads per
     // lane (232 registers) and the rest of the register file keeps a stage's operands in flight:
-    //   role A (j < 16, k = j): prenet-1 (folded: reads o2) tile k, GRU-1 owner (folded reset-gate tile k, local
-    //        concat-projection tile k for the residual, folded candidate tile k, owns h1 / o1), update-gate tiles of the
-    //        attention GRU and of GRU-2, output tiles 16..24 (k < 9);
+    //   role A (j < 16, k = j): prenet-1 (folded: reads o2) tile k, query tile k, GRU-1 owner (folded reset-gate tile k,
+    //        folded candidate tile k, owns h1 / o1), update-gate tiles of the attention GRU and of GRU-2, output tiles
+    //        16..24 (k < 9);
     //   role B (j >= 16, k = j-16): prenet-2 tile k (k < 8), attention-GRU owner (reset tile k, candidate tile k, owns
-    //        h_att), query tile k, GRU-2 owner (reset tile k, candidate tile k, owns h2), update-gate tiles of GRU-1
-    //        (folded), output tiles 0..15.
+    //        h_att), GRU-2 owner (reset tile k, candidate tile k, owns h2), update-gate tiles of GRU-1 (folded), the
+    //        concat projection d0 tile k (only the residual o1 = h1 + d0 needs it: off the chain), output tiles 0..15.
     const bool roleA = j < 16;
     const int k = roleA ? j : j - 16;
     enum { SL_A6 = 0, SL_G12, SL_G8, SL_X8A, SL_X8B0, SL_X8B1, SL_X12, SL_O4, SL_GO, SL_COUNT };
@@ -280,14 +289,16 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
     pd_load_w<8>(g8, a.Wp[ST_G2G], t_g8, 32, 32, wave, lane);
     pd_load_w<8>(x8a, a.Wp[roleA ? ST_PRE1 : ST_G2C], k, 16, 32, wave, lane);
     if (roleA) {
-        pd_load_w<8>(x8b, a.Wp[ST_PROJ], k, 16, 32, wave, lane);
+        pd_load_w<4>(pd_sub<4>(x8b, 0), a.Wp[ST_QUERY], k, 16, 16, wave, lane);
+#pragma unroll
+        for (int i = 4; i < 8; ++i) x8b[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         pd_load_w<12>(x12, a.Wp[ST_G1C], k, 16, 48, wave, lane);
     } else {
-        pd_load_w<4>(pd_sub<4>(x8b, 0), a.Wp[ST_QUERY], k, 16, 16, wave, lane);
-        pd_load_w<4>(pd_sub<4>(x8b, 4), a.Wp[ST_PRE2], k, 8, 16, wave, lane);
+        pd_load_w<8>(x8b, a.Wp[ST_PROJ], k, 16, 32, wave, lane);
         pd_load_w<6>(pd_sub<6>(x12, 0), a.Wp[ST_ATTC], k, 16, 24, wave, lane);
+        pd_load_w<4>(pd_sub<4>(x12, 6), a.Wp[ST_PRE2], k, 8, 16, wave, lane);
 #pragma unroll
-        for (int i = 6; i < 12; ++i) x12[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 10; i < 12; ++i) x12[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     pd_load_w<4>(o4, a.Wp[ST_OUT], t_out, 25, 16, wave, lane);
     for (int i = tid; i < SL_COUNT * 16; i += PD_THREADS) {
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
             case SL_G12: bp = a.bias[ST_G1G]; tile = t_g12; nt = 32; break;
             case SL_G8: bp = a.bias[ST_G2G]; tile = t_g8; nt = 32; break;
             case SL_X8A: bp = a.bias[roleA ? ST_PRE1 : ST_G2C]; break;
-            case SL_X8B0: bp = roleA ? a.bias[ST_PROJ] : nullptr; break;
+            case SL_X8B0: bp = roleA ? nullptr : a.bias[ST_PROJ]; break;
             case SL_X8B1: bp = roleA ? nullptr : a.bias[ST_PRE2]; nt = 8; break;
             case SL_X12: bp = a.bias[roleA ? ST_G1C : ST_ATTC]; break;
             case SL_O4: bp = a.bias[ST_OUT]; tile = t_out; nt = 25; break;
@@ -314,10 +325,31 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
     const int t_lo = hf ? Th : 0, t_n = hf ? a.T_in - Th : Th;           // this half's score range
     const float* keys_g = a.keys + ((size_t)(att_on ? b_att : 0) * a.T_in + t_lo) * 256;
     const float* vals_g = a.values + (size_t)(att_on ? b_att : 0) * a.T_in * 256 + hf * 128;
+    // Fast score path: tanh(k + q) = 1 - 2 / (E_k E_q + 1) with E_x = 2^(2 log2(e) x). E_k is stored instead of k when
+    // every |k| of this half is below 40 (E_k finite and normal; a product that overflows or underflows still gives the
+    // right +-1). A step whose |q| reaches 40 reads the plain keys from global memory instead.
+    bool keys_exp = false;
     if (att_on) {
-        if (a.lds_keys)
-            for (int i = tid; i < t_n * 64; i += PD_THREADS)
-                reinterpret_cast<float4*>(keys_s)[i] = reinterpret_cast<const float4*>(keys_g)[i];
+        if (a.lds_keys) {
+            float kmax = 0.f;
+            for (int i = tid; i < t_n * 64; i += PD_THREADS) {
+                const float4 kv = reinterpret_cast<const float4*>(keys_g)[i];
+                kmax = fmaxf(fmaxf(kmax, fmaxf(fabsf(kv.x), fabsf(kv.y))), fmaxf(fabsf(kv.z), fabsf(kv.w)));
+            }
+            kmax = wave_max(kmax);
+            if (lane == 0) wsum_s[4 + wave] = kmax;
+            __syncthreads();
+            kmax = fmaxf(fmaxf(wsum_s[4], wsum_s[5]), fmaxf(wsum_s[6], wsum_s[7]));
+            keys_exp = kmax < 40.f;      // (NaN keys fail the test and keep the plain path)
+            constexpr float c2 = 2.8853900817779268f;
+            for (int i = tid; i < t_n * 64; i += PD_THREADS) {
+                float4 kv = reinterpret_cast<const float4*>(keys_g)[i];
+                if (keys_exp)
+                    kv = make_float4(__builtin_amdgcn_exp2f(kv.x * c2), __builtin_amdgcn_exp2f(kv.y * c2),
+                                     __builtin_amdgcn_exp2f(kv.z * c2), __builtin_amdgcn_exp2f(kv.w * c2));
+                reinterpret_cast<float4*>(keys_s)[i] = kv;
+            }
+        }
         if (a.lds_vals)
             for (int i = tid; i < a.T_in * 32; i += PD_THREADS)
                 reinterpret_cast<float4*>(vals_s)[i] =
@@ -327,7 +359,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
     __syncthreads();
 
     // tiles this workgroup owns across steps (wave 0 only uses them): role A h1, d0, o1; role B h_att, h2
-    f32x4 hA_t = {0.f, 0.f, 0.f, 0.f}, hB_t = hA_t, d0_t = hA_t, o1_t = hA_t;   // A: hA=h1 ; B: hA=h_att, hB=h2
+    f32x4 hA_t = {0.f, 0.f, 0.f, 0.f}, hB_t = hA_t, o1_t = hA_t;   // A: hA=h1 ; B: hA=h_att, hB=h2
     const unsigned te = (unsigned)((k * 4 + lq) * Bpad + lb) * 8u;          // float offset of this lane's quad in tile k
     const unsigned te16 = (unsigned)(((16 + k) * 4 + lq) * Bpad + lb) * 8u; // ... in tile 16+k (output frames)
     const unsigned st_stride = (unsigned)(256 * Bpad * 2);                   // one 256-wide granule buffer
@@ -369,7 +401,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
         if (s) PD_OUT(s - 1, Tp + 12u);       // previous step's frames: off the dependency chain
         if (!roleA && k < 8) {
             const Segs sg{a.o_p1, T + 1u, 16, 0u, 0u, 16, 0u, 0u};
-            f32x4 v = PD_MMA(4, 0, pd_sub<4>(x8b, 4), sg, 16, ex);
+            f32x4 v = PD_MMA(4, 0, pd_sub<4>(x12, 6), sg, 16, ex);
             if (wave == 0) pd_stg(rs, a.o_p2 + te, relu4(v + PD_BIAS(SL_X8B1)), T + 2u);
         }
         PD_STAMP();
@@ -394,10 +426,12 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
                 hA_t = ug * hA_t + (1.f - ug) * c;
                 pd_stg(rs, hc + te, hA_t, T + 4u);
             }
-            PD_STAMP();
+        }
+        PD_STAMP();
+        if (roleA) {
             // ---- stage 4: attention query (decoder.py:20)
             const Segs sq{hc, T + 4u, 16, 0u, 0u, 16, 0u, 0u};
-            v = PD_MMA(4, 0, pd_sub<4>(x8b, 0), sq, 16, ex);
+            f32x4 v = PD_MMA(4, 0, pd_sub<4>(x8b, 0), sq, 16, ex);
             if (wave == 0) pd_stg(rs, a.o_q + te, v, T + 5u);
         }
         PD_STAMP();
@@ -430,7 +464,35 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
                 }
             };
             __syncthreads();                       // e_s free (previous step's context done)
-            if (a.lds_keys) {
+            const bool q_small = !__any(!(fabsf(qq.x) < 40.f && fabsf(qq.y) < 40.f && fabsf(qq.z) < 40.f && fabsf(qq.w) < 40.f));
+            if (keys_exp && q_small) {
+                // e_t = sum_d v_d (1 - 2 / (E_k E_q + 1)) = sum_d v_d - 2 sum_d v_d / (E_k E_q + 1)
+                constexpr float c2 = 2.8853900817779268f;
+                const f32x4 eq = {__builtin_amdgcn_exp2f(qq.x * c2), __builtin_amdgcn_exp2f(qq.y * c2),
+                                  __builtin_amdgcn_exp2f(qq.z * c2), __builtin_amdgcn_exp2f(qq.w * c2)};
+                const float sv = (v_att.x + v_att.y) + (v_att.z + v_att.w);
+                const float4* kp = reinterpret_cast<const float4*>(keys_s);
+                float4 k0 = kp[wave * 64 + lane];
+                float4 k1 = kp[(wave + PD_WAVES < t_n ? wave + PD_WAVES : wave) * 64 + lane];
+                for (int t = wave; t < t_n; t += 2 * PD_WAVES) {
+                    const int t1 = t + PD_WAVES, tn = t + 2 * PD_WAVES, tn1 = tn + PD_WAVES;
+                    // next pair's keys in flight under this pair's arithmetic
+                    const float4 n0 = kp[(tn < t_n ? tn : t) * 64 + lane];
+                    const float4 n1 = kp[(tn1 < t_n ? tn1 : t) * 64 + lane];
+                    float s0 = v_att.x * __builtin_amdgcn_rcpf(fmaf(k0.x, eq.x, 1.f)) + v_att.y * __builtin_amdgcn_rcpf(fmaf(k0.y, eq.y, 1.f)) +
+                               v_att.z * __builtin_amdgcn_rcpf(fmaf(k0.z, eq.z, 1.f)) + v_att.w * __builtin_amdgcn_rcpf(fmaf(k0.w, eq.w, 1.f));
+                    float s1 = v_att.x * __builtin_amdgcn_rcpf(fmaf(k1.x, eq.x, 1.f)) + v_att.y * __builtin_amdgcn_rcpf(fmaf(k1.y, eq.y, 1.f)) +
+                               v_att.z * __builtin_amdgcn_rcpf(fmaf(k1.z, eq.z, 1.f)) + v_att.w * __builtin_amdgcn_rcpf(fmaf(k1.w, eq.w, 1.f));
+                    s0 = wave_sum(fmaf(-2.f, s0, sv));
+                    s1 = wave_sum(fmaf(-2.f, s1, sv));
+                    if (lane == 0) {
+                        e_s[t_lo + t] = s0;
+                        if (t1 < t_n) e_s[t_lo + t1] = s1;
+                    }
+                    k0 = n0;
+                    k1 = n1;
+                }
+            } else if (a.lds_keys && !keys_exp) {
                 const float4* kp = reinterpret_cast<const float4*>(keys_s);
                 for (int t = wave; t < t_n; t += 2 * PD_WAVES) {
                     const int t1 = t + PD_WAVES;
@@ -464,26 +526,25 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
             }
             __syncthreads();
             PD_STAMP();
-            if (wave == 0) {   // softmax over all T_in (max-subtracted, as tf.nn.softmax); both halves compute it
+            // softmax over all T_in (max-subtracted, as tf.nn.softmax); both halves compute it. Every wave finds the max
+            // itself, the threads share the exponentials; the 1/sum factor is applied to the context and to the
+            // alignment row at the end
+            float inv;
+            {
                 float mx = -INFINITY;
                 for (int t = lane; t < a.T_in; t += 64) mx = fmaxf(mx, e_s[t]);
                 mx = wave_max(mx);
                 float sum = 0.f;
-                for (int t = lane; t < a.T_in; t += 64) {
-                    const float p = expf(e_s[t] - mx);
-                    e_s[t] = p;
+                for (int t = tid; t < a.T_in; t += PD_THREADS) {
+                    const float p = __builtin_amdgcn_exp2f((e_s[t] - mx) * 1.4426950408889634f);
+                    p_s[t] = p;
                     sum += p;
                 }
                 sum = wave_sum(sum);
-                const float inv = 1.f / sum;
-                float* arow = a.alignS + ((size_t)s * a.B + b_att) * a.T_in;
-                for (int t = lane; t < a.T_in; t += 64) {
-                    const float p = e_s[t] * inv;
-                    e_s[t] = p;
-                    if (hf == 0) arow[t] = p;
-                }
+                if (lane == 0) wsum_s[wave] = sum;
+                __syncthreads();
+                inv = 1.f / ((wsum_s[0] + wsum_s[1]) + (wsum_s[2] + wsum_s[3]));
             }
-            __syncthreads();
             PD_STAMP();
             // context, this half's 128 channels: lane = (t parity, channel quad), waves stride t by 8
             const int dq = lane & 31, tp = lane >> 5;
@@ -492,14 +553,14 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
                 const float4* vp = reinterpret_cast<const float4*>(vals_s);
                 for (int t = 2 * wave + tp; t < a.T_in; t += 2 * PD_WAVES) {
                     const float4 x = vp[t * 32 + dq];
-                    const float p = e_s[t];
+                    const float p = p_s[t];
                     acc.x = fmaf(p, x.x, acc.x); acc.y = fmaf(p, x.y, acc.y);
                     acc.z = fmaf(p, x.z, acc.z); acc.w = fmaf(p, x.w, acc.w);
                 }
             } else {
                 for (int t = 2 * wave + tp; t < a.T_in; t += 2 * PD_WAVES) {
                     const float4 x = reinterpret_cast<const float4*>(vals_g + (size_t)t * 256)[dq];
-                    const float p = e_s[t];
+                    const float p = p_s[t];
                     acc.x = fmaf(p, x.x, acc.x); acc.y = fmaf(p, x.y, acc.y);
                     acc.z = fmaf(p, x.z, acc.z); acc.w = fmaf(p, x.w, acc.w);
                 }
@@ -510,7 +571,11 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
                 f32x4 c = red[tid] + red[32 + tid];
 #pragma unroll
                 for (int ww = 1; ww < PD_WAVES; ++ww) c += red[ww * 64 + tid] + red[ww * 64 + 32 + tid];
-                pd_stg(rs, o_ctx + (unsigned)((hf * 32 + tid) * Bpad + b_att) * 8u, c, T + 7u);
+                pd_stg(rs, o_ctx + (unsigned)((hf * 32 + tid) * Bpad + b_att) * 8u, c * inv, T + 7u);
+            }
+            if (hf == 0) {      // alignment row (tacotron.py:51 gets it transposed at the end): off the chain
+                float* arow = a.alignS + ((size_t)s * a.B + b_att) * a.T_in;
+                for (int t = tid; t < a.T_in; t += PD_THREADS) arow[t] = p_s[t] * inv;
             }
             PD_STAMP();
         }
@@ -526,20 +591,22 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
             }
         }
         PD_STAMP();
-        if (roleA) {
-            // d0 = W_p [h_att ; ctx] + b_p is only needed for the residual o1 = h1 + d0: computed here, by the
-            // workgroup that consumes it, while the reset gates of the other workgroups arrive
+        if (!roleA) {
+            // d0 = W_p [h_att ; ctx] + b_p is only needed for the residual o1 = h1 + d0: role B computes it while
+            // role A is busy with the candidate, which picks its tile up with its update gate
             const Segs sp{hc, T + 4u, 16, o_ctx, T + 7u, 32, 0u, 0u};
             f32x4 v = PD_MMA(8, 0, x8b, sp, 32, ex);
-            if (wave == 0) d0_t = v + PD_BIAS(SL_X8B0);
+            if (wave == 0) pd_stg(rs, a.o_d0 + te, v + PD_BIAS(SL_X8B0), T + 8u);
+        } else {
             ex[0].off = a.o_u + st_stride + te; ex[0].tag = T + 9u;
+            ex[1].off = a.o_d0 + te; ex[1].tag = T + 8u;
             const Segs sg{hc, T + 4u, 16, o_ctx, T + 7u, 32, a.o_rh + st_stride, T + 9u};
-            v = PD_MMA(12, 1, x12, sg, 48, ex);
+            f32x4 v = PD_MMA(12, 2, x12, sg, 48, ex);
             if (wave == 0) {
                 const f32x4 ug = ex[0].val;
                 const f32x4 c = tanh4(v + PD_BIAS(SL_X12));
                 hA_t = ug * hA_t + (1.f - ug) * c;
-                o1_t = hA_t + d0_t;
+                o1_t = hA_t + ex[1].val;
                 pd_stg(rs, a.o_h1 + cur + te, hA_t, T + 10u);
                 pd_stg(rs, a.o_o1 + te, o1_t, T + 10u);
             }
@@ -588,7 +655,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
 size_t dec_persistent_lds_bytes(int T_in, int* lds_keys, int* lds_vals) {
     const size_t cap = 160 * 1024;
     const int T4 = (T_in + 3) & ~3, Th = (T_in + 1) >> 1;
-    size_t base = 8192 + (size_t)ST_COUNT * 16 * 4 + (size_t)T4 * 4;
+    size_t base = 8192 + (size_t)ST_COUNT * 16 * 4 + (size_t)T4 * 8 + 32;
     base = (base + 15) & ~(size_t)15;
     const size_t kb = (size_t)Th * 1024, vb = (size_t)T_in * 512;
     *lds_keys = base + kb <= cap;

@@ -127,7 +127,7 @@ struct DecPersistArgs {
     const float* values;      // [B, T_in, 256] (encoder outputs)
     float* region;
     unsigned region_bytes;
-    unsigned o_hc, o_h1, o_h2, o_p1, o_p2, o_rh, o_u, o_q, o_o1, o_o2, o_e, o_outQ;   // o_hc: 2 x [h_att ; ctx]
+    unsigned o_hc, o_h1, o_h2, o_p1, o_p2, o_rh, o_u, o_q, o_d0, o_o1, o_o2, o_e, o_outQ;   // o_hc: 2 x [h_att ; ctx]
     float* alignS;            // [S][B][T_in]
     unsigned long long* sync; // {unused, abort word}, zeroed per call
     int B, Bpad, T_in, S;
