@@ -99,6 +99,7 @@ struct taco_ctx {
     ConvW mem_layer, lin_dense;
     DecW pre1, pre2, att_g, att_c, query, proj, g1_g, g1_c, g2_g, g2_c, outp;
     DecW pre1_f, g1_g_f, g1_c_f;   // folded forms for the persistent decoder (Loader::dec_fold)
+    DecW att_g_p, g2_g_p;          // row-reordered copies (early inputs first) for the persistent decoder
     float* attn_v = nullptr;
     float* twiddle = nullptr;
     float* window = nullptr;
@@ -310,8 +311,27 @@ struct Loader {
     // [0, Nl) of the next layer's kernel Wn ([Nl + Kr, N]) is pre-multiplied into it, so that the next layer reads
     // L's INPUT and L leaves the step's dependency chain:  [x ; r] -> x (Wl Wn[0:Nl]) + r Wn[Nl:] + (bn + bl Wn[0:Nl]).
     // `lcol0` selects columns [lcol0, lcol0 + Nl) of Wl / bl (the last of the r output frames). Products in fp64.
+    // `order`: row blocks (start, length) of the folded matrix [x rows ; r rows] in the order the kernel wants them
+    // (inputs that arrive early first); empty = as is.
+    typedef std::vector<std::pair<int, int>> RowOrder;
+    static std::vector<float> reorder_rows(const std::vector<float>& h, int N, const RowOrder& order) {
+        if (order.empty()) return h;
+        std::vector<float> o;
+        o.reserve(h.size());
+        for (auto& b : order) o.insert(o.end(), h.begin() + (size_t)b.first * N, h.begin() + (size_t)(b.first + b.second) * N);
+        return o;
+    }
+    // plain [K, N] kernel with its row blocks reordered (persistent decoder copies of unfolded layers)
+    bool dec_perm(DecW& w, const std::string& kname, const DecW& bias_of, int K, int N, const RowOrder& order) {
+        const TacoWeightEntry* e = get(kname, {K, N});
+        if (!e) return false;
+        const std::vector<float> h = reorder_rows(std::vector<float>(e->data, e->data + (size_t)K * N), N, order);
+        if (h.size() != (size_t)K * N || !dec_pack(w, h.data(), K, N)) return false;
+        w.bias = bias_of.bias;
+        return true;
+    }
     bool dec_fold(DecW& w, const TacoWeightEntry* Wl, const TacoWeightEntry* bl, int lcol0, int Nl,
-                  const TacoWeightEntry* Wn, const TacoWeightEntry* bn, bool rest_first) {
+                  const TacoWeightEntry* Wn, const TacoWeightEntry* bn, bool rest_first, const RowOrder& order = {}) {
         const int Kl = (int)Wl->dims[0], ldl = (int)Wl->dims[1];
         const int Kn = (int)Wn->dims[0], N = (int)Wn->dims[1], Kr = Kn - Nl;
         // rows of Wn fed by L: [0, Nl) when the layer's input is [L(x) ; r], [Kr, Kn) when it is [r ; L(x)]
@@ -336,7 +356,8 @@ struct Loader {
                 for (int j = 0; j < Nl; ++j) a += (double)bl->data[lcol0 + j] * (double)Wn->data[(size_t)(l0 + j) * N + n];
             bias[n] = (float)a;
         }
-        if (!dec_pack(w, h.data(), Kl + Kr, N)) return false;
+        const std::vector<float> hp = reorder_rows(h, N, order);
+        if (hp.size() != h.size() || !dec_pack(w, hp.data(), Kl + Kr, N)) return false;
         w.bias = upload(bias);
         return w.bias != nullptr;
     }
@@ -578,9 +599,16 @@ extern "C" int taco_create(const TacoHParams* hp, const TacoWeightEntry* weights
         const TacoWeightEntry* Wc = L.get(g1s + "candidate/kernel", {2 * D, D});
         const TacoWeightEntry* bc = L.get(g1s + "candidate/bias", {D});
         ok = Wo && bo && W1 && b1 && Wp && bp && Wg && bg && Wc && bc &&
-             L.dec_fold(c->pre1_f, Wo, bo, NR - p.num_mels, p.num_mels, W1, b1, false) &&
-             L.dec_fold(c->g1_g_f, Wp, bp, 0, (int)D, Wg, bg, false) &&
-             L.dec_fold(c->g1_c_f, Wp, bp, 0, (int)D, Wc, bc, false);
+             // K orders: inputs that are ready early first, the one a stage waits for last
+             L.dec_fold(c->pre1_f, Wo, bo, NR - p.num_mels, p.num_mels, W1, b1, false,
+                        {{(int)D, G2}, {0, (int)D}}) &&                                        // [ctx ; o2]
+             L.dec_fold(c->g1_g_f, Wp, bp, 0, (int)D, Wg, bg, false,
+                        {{0, (int)A}, {(int)A + G2, (int)D}, {(int)A, G2}}) &&                  // [h_att ; h1 ; ctx]
+             L.dec_fold(c->g1_c_f, Wp, bp, 0, (int)D, Wc, bc, false) &&                        // [h_att ; ctx ; r.h1]
+             L.dec_perm(c->att_g_p, ATTW + "decoder_prenet_wrapper/gru_cell/gates/kernel", c->att_g,
+                        p.prenet_depth2 + (int)A, 2 * (int)A, {{p.prenet_depth2, (int)A}, {0, p.prenet_depth2}}) &&   // [h_att ; p2]
+             L.dec_perm(c->g2_g_p, DEC + "multi_rnn_cell/cell_2/gru_cell/gates/kernel", c->g2_g, 2 * (int)D, 2 * (int)D,
+                        {{(int)D, (int)D}, {0, (int)D}});                                      // [h2 ; o1]
     }
     ok = ok && L.cbhg(c->post, "post_cbhg");
     ok = ok && L.conv(c->lin_dense, "dense/kernel", "dense/bias", 0, 2 * p.decoder_gru_cells, p.num_freq);
@@ -849,8 +877,8 @@ static int decode_impl(taco_ctx* c, const float* enc_out, int B, int T_in, int S
         c->dbg_stamps = reinterpret_cast<unsigned long long*>(pregion + pregion_floats);
         (void)hipMemsetAsync(sync, 0, 128, s);
         DecPersistArgs a{};
-        const DecW* W[11] = {&c->pre1_f, &c->pre2, &c->att_g, &c->att_c, &c->query, &c->proj,
-                             &c->g1_g_f, &c->g1_c_f, &c->g2_g, &c->g2_c, &c->outp};
+        const DecW* W[11] = {&c->pre1_f, &c->pre2, &c->att_g_p, &c->att_c, &c->query, &c->proj,
+                             &c->g1_g_f, &c->g1_c_f, &c->g2_g_p, &c->g2_c, &c->outp};
         for (int i = 0; i < 11; ++i) { a.Wp[i] = W[i]->Wp; a.bias[i] = W[i]->bias; }
         a.bias_pre1_go = c->pre1.bias;
         a.attn_v = c->attn_v; a.keys = d.keys; a.values = enc_out;

@@ -108,14 +108,15 @@ struct Spin {
     }
 };
 
-// One stage's matrix product for this workgroup's 16x16 tile: wave w owns k16-steps [w*CH, (w+1)*CH), fetched
-// (and re-fetched until every granule carries the expected tag) PD_BATCH steps at a time. Wave 0 can fetch up to
+// One stage's matrix product for this workgroup's 16x16 tile: wave w owns k16-steps w, w+4, w+8, ... (CH of them), so
+// every wave has an equal share of each K segment; they are fetched (and re-fetched until every granule carries the
+// expected tag) PD_BATCH steps at a time, the segments in K order: the stage's late input is its last segment. Wave 0 can fetch up to
 // two more quads of its epilogue (update gate, residual) in the same poll loop of its first batch.
 // Returns the reduced tile fragment in wave 0 (lane: column b = lane&15, rows 4*(lane>>4)..+3).
 struct Extra { unsigned off, tag; f32x4 val; };
 // the K dimension of a stage is up to three consecutive segments of k16-steps, each its own granule buffer and tag
 struct Segs { unsigned off0, tag0; int e0; unsigned off1, tag1; int e1; unsigned off2, tag2; };
-template <int CH, int NX>
+template <int CH, int NX, int E0 = PD_BATCH>   // E0: size of the first batch (so that later batches line up with a segment)
 __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_rsrc_t rs, const Segs sg, int nk16,
                                         int Bpad, int lb, int lq, int wave_v, int lane, f32x4* red, Spin& spin,
                                         Extra* ex) {
@@ -123,7 +124,11 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
     const unsigned lane_bytes = (unsigned)(lq * Bpad + lb) * 32u;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int h = 0; h < CH; h += PD_BATCH) {
+    for (int hb = 0; hb < CH + PD_BATCH; hb += PD_BATCH) {
+        // batches [0, E0), [E0, E0 + PD_BATCH), ...
+        const int h = hb == 0 ? 0 : hb - PD_BATCH + E0;
+        const int hn = hb == 0 ? E0 : PD_BATCH;
+        if (h >= CH) break;
         GQuad g[PD_BATCH];
         GQuad gx[NX > 0 ? NX : 1];
         // a k16-step that has arrived is not fetched again: a retry only re-reads what is still missing
@@ -136,8 +141,8 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
             bool ok = true;
 #pragma unroll
             for (int i = 0; i < PD_BATCH; ++i) {
-                const int ks = wave * CH + h + i;
-                if (h + i < CH && ks < nk16 && !have[i]) {
+                const int ks = (h + i) * PD_WAVES + wave;
+                if (i < hn && h + i < CH && ks < nk16 && !have[i]) {
                     const int s = ks < sg.e0 ? 0 : (ks < sg.e1 ? 1 : 2);
                     const unsigned off = s == 0 ? sg.off0 : (s == 1 ? sg.off1 : sg.off2);
                     const int kb = s == 0 ? 0 : (s == 1 ? sg.e0 : sg.e1);
@@ -152,8 +157,8 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
             }
 #pragma unroll
             for (int i = 0; i < PD_BATCH; ++i) {
-                const int ks = wave * CH + h + i;
-                if (h + i < CH && ks < nk16 && !have[i]) {
+                const int ks = (h + i) * PD_WAVES + wave;
+                if (i < hn && h + i < CH && ks < nk16 && !have[i]) {
                     const int s = ks < sg.e0 ? 0 : (ks < sg.e1 ? 1 : 2);
                     const unsigned tag = s == 0 ? sg.tag0 : (s == 1 ? sg.tag1 : sg.tag2);
                     have[i] = __all(gq_ok(g[i], tag));
@@ -179,8 +184,8 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
         }
 #pragma unroll
         for (int i = 0; i < PD_BATCH; ++i) {
-            const int ks = wave * CH + h + i;
-            if (h + i < CH && ks < nk16) {
+            const int ks = (h + i) * PD_WAVES + wave;
+            if (i < hn && h + i < CH && ks < nk16) {
                 const f32x4 x = gq_val(g[i]);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[h + i].x, x.x, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[h + i].y, x.y, acc1, 0, 0, 0);
@@ -222,7 +227,7 @@ __device__ __forceinline__ void pd_load_w(float4 (&w)[CH], const float* Wp, int 
                                           int lane) {
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-        const int ks = wave * CH + i;
+        const int ks = i * PD_WAVES + wave;
         w[i] = (tile < ntiles && ks < nk16)
                    ? reinterpret_cast<const float4*>(Wp)[((size_t)tile * nk16 + ks) * 64 + lane]
                    : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
         // ---- stage 0/1: decoder prenet (rnn_wrappers.py:25): relu(W1 [prev frame; ctx] + b1) with the output projection
         // folded in (prev frame = last of the r frames of o2), relu(W2 . + b2); step 0 feeds the <GO> frame: o2 = 0, own bias
         if (roleA) {
-            const Segs sg{a.o_o2, s ? Tp + 12u : 0u, 16, o_ctxp, s ? Tp + 7u : 0u, 32, 0u, 0u};
+            const Segs sg{o_ctxp, s ? Tp + 7u : 0u, 16, a.o_o2, s ? Tp + 12u : 0u, 32, 0u, 0u};
             f32x4 v = PD_MMA(8, 0, x8a, sg, 32, ex);
             if (wave == 0) pd_stg(rs, a.o_p1 + te, relu4(v + PD_BIAS(s ? SL_X8A : SL_GO)), T + 1u);
         }
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
         PD_STAMP();
         // ---- stage 2/3: attention GRU (rnn_wrappers.py:26): gates (A: update tile, B: reset tile), candidate (B)
         {
-            const Segs sg{a.o_p2, T + 2u, 8, hcp, s ? Tp + 4u : 0u, 24, 0u, 0u};
+            const Segs sg{hcp, s ? Tp + 4u : 0u, 16, a.o_p2, T + 2u, 24, 0u, 0u};
             f32x4 v = PD_MMA(6, 0, a6, sg, 24, ex);
             if (wave == 0) {
                 const f32x4 g = sig4(v + PD_BIAS(SL_A6));
@@ -419,7 +424,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
         if (!roleA) {
             ex[0].off = a.o_u + te; ex[0].tag = T + 3u;
             const Segs sg{a.o_p2, T + 2u, 8, a.o_rh, T + 3u, 24, 0u, 0u};
-            f32x4 v = PD_MMA(6, 1, pd_sub<6>(x12, 0), sg, 24, ex);
+            f32x4 v = pd_mma<6, 1, 2>(pd_sub<6>(x12, 0), rs, sg, 24, Bpad, lb, lq, wave, lane, red, spin, ex);
             if (wave == 0) {
                 const f32x4 ug = ex[0].val;
                 const f32x4 c = tanh4(v + PD_BIAS(SL_X12));
@@ -582,7 +587,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
         // ---- stage 8/9: residual GRU 1 (decoder.py:30) with the concat projection (rnn_wrappers.py:53, decoder.py:29)
         // folded in: gates (A: reset tile, B: update tile) and candidate (A) read [h_att ; ctx ; h1] / [h_att ; ctx ; r.h1]
         {
-            const Segs sg{hc, T + 4u, 16, o_ctx, T + 7u, 32, a.o_h1 + prv, s ? Tp + 10u : 0u};
+            const Segs sg{hc, T + 4u, 16, a.o_h1 + prv, s ? Tp + 10u : 0u, 32, o_ctx, T + 7u};
             f32x4 v = PD_MMA(12, 0, g12, sg, 48, ex);
             if (wave == 0) {
                 const f32x4 g = sig4(v + PD_BIAS(SL_G12));
@@ -614,7 +619,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
         PD_STAMP();
         // ---- stage 10/11: residual GRU 2 (decoder.py:31): gates (A: update tile, B: reset tile), candidate (B)
         {
-            const Segs sg{a.o_o1, T + 10u, 16, a.o_h2 + prv, s ? Tp + 12u : 0u, 32, 0u, 0u};
+            const Segs sg{a.o_h2 + prv, s ? Tp + 12u : 0u, 16, a.o_o1, T + 10u, 32, 0u, 0u};
             f32x4 v = PD_MMA(8, 0, g8, sg, 32, ex);
             if (wave == 0) {
                 const f32x4 g = sig4(v + PD_BIAS(SL_G8));
