@@ -129,6 +129,8 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
         const int h = hb == 0 ? 0 : hb - PD_BATCH + E0;
         const int hn = hb == 0 ? E0 : PD_BATCH;
         if (h >= CH) break;
+        const bool last = h + hn >= CH;      // the epilogue operands (update gate, residual) ride with the last batch:
+                                             // a late one must not hold back K segments that are already there
         GQuad g[PD_BATCH];
         GQuad gx[NX > 0 ? NX : 1];
         // a k16-step that has arrived is not fetched again: a retry only re-reads what is still missing
@@ -150,7 +152,7 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
                     g[i] = pd_ldg2(rs, lane_bytes, uni);
                 }
             }
-            if (NX > 0 && h == 0 && wave == 0) {
+            if (NX > 0 && last && wave == 0) {
 #pragma unroll
                 for (int i = 0; i < NX; ++i)
                     if (!havex[i]) gx[i] = pd_ldg(rs, ex[i].off);
@@ -165,7 +167,7 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
                     ok = ok && have[i];
                 }
             }
-            if (NX > 0 && h == 0 && wave == 0) {
+            if (NX > 0 && last && wave == 0) {
 #pragma unroll
                 for (int i = 0; i < NX; ++i)
                     if (!havex[i]) {
@@ -178,7 +180,7 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
 #ifdef PD_STAMPS
         if (wave_v == 0 && lane == 0) spin.stamp(1);
 #endif
-        if (NX > 0 && h == 0 && wave == 0) {
+        if (NX > 0 && last && wave == 0) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) ex[i].val = gq_val(gx[i]);
         }
@@ -556,6 +558,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             if (a.lds_vals) {
                 const float4* vp = reinterpret_cast<const float4*>(vals_s);
+#pragma unroll 5
                 for (int t = 2 * wave + tp; t < a.T_in; t += 2 * PD_WAVES) {
                     const float4 x = vp[t * 32 + dq];
                     const float p = p_s[t];
