@@ -1079,7 +1079,9 @@ extern "C" int taco_decode_status(taco_handle h) {
     if (!h->last_sync_groups) return 0;
     HIP_OK(hipSetDevice(h->device));
     unsigned long long w = 0;
-    HIP_OK(hipMemcpy(&w, h->sync_words, 8, hipMemcpyDeviceToHost));
+    unsigned info[4] = {0, 0, 0, 0};
+    HIP_OK(hipMemcpy(info, h->sync_words, 16, hipMemcpyDeviceToHost));
+    w = (unsigned long long)info[1] << 32;
 #ifdef PD_STAMPS
     if (h->dbg_stamps) {
         unsigned long long st[256];
@@ -1092,7 +1094,9 @@ extern "C" int taco_decode_status(taco_handle h) {
         fprintf(stderr, "\n");
     }
 #endif
-    if (w >> 32) return fail("persistent decoder: a bounded inter-workgroup wait timed out; outputs are invalid");
+    if (w >> 32)
+        return fail("persistent decoder: a bounded inter-workgroup wait timed out; outputs are invalid "
+                    "(first: workgroup %u waiting for step %u stage %u)", info[2], (info[3] - 1) / 13, (info[3] - 1) % 13);
     return 0;
 }
 

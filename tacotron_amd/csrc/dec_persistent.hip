@@ -34,7 +34,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int PD_THREADS = 256;   // one wave per SIMD: each wave may use the whole 512-entry register file
 constexpr int PD_WAVES = 4;
-constexpr unsigned PD_SPIN_LIMIT = 1u << 21;   // polls (>= ~0.5 us each) before a wait gives up
+constexpr unsigned long long PD_WAIT_LIMIT_TICKS = 1000000000ull;   // 10 s of s_memrealtime (100 MHz) per wait
 constexpr int PD_BATCH = 4;                    // k16-steps fetched (and tag-checked) together
 constexpr int PD_STAGES = 13;
 #ifndef PD_STAMP_WG
@@ -81,25 +81,36 @@ __device__ __forceinline__ void pd_stg(__amdgpu_buffer_rsrc_t rs, unsigned float
     __builtin_amdgcn_raw_buffer_store_b128(hi, rs, float_off * 4u + 16u, 0, 16);
 }
 
-// Bounded wait bookkeeping: a wave that has polled PD_SPIN_LIMIT times sets the launch's abort word and goes on
-// with what it has; every wave looks at the abort word now and then and stops waiting once it is set.
+// Bounded wait bookkeeping: a wave whose single wait has lasted PD_WAIT_LIMIT_TICKS of the 100 MHz real-time clock
+// sets the launch's abort word and goes on with what it has; every wave looks at the abort word (and the clock) every
+// 1024 failed polls and stops waiting once it is set. The bound is on wall time per wait, not on the number of polls:
+// a launch that shares the GPU with other queues can be time-sliced and run orders of magnitude slower for a while
+// (seen on the first launch of a new stream beside a busy one) without anything being wrong.
 struct Spin {
-    unsigned* abort_word;
-    unsigned n;
+    unsigned* abort_word;      // [0] abort flag, [1] workgroup and [2] tag of the first wait that ran out (diagnostics)
+    unsigned n;                // failed polls of the current wait
     bool dead;
+    unsigned where;            // tag the current wait is for
+    unsigned long long t0;
 #ifdef PD_STAMPS
     unsigned long long* st_lds; int stamp_i; bool stamp_on;    // diagnostic builds: stamps collected in LDS
     __device__ __forceinline__ void stamp(unsigned long long flag) {
         if (stamp_on && stamp_i < 250) st_lds[stamp_i++] = __builtin_amdgcn_s_memrealtime() | (flag << 60);
     }
 #endif
+    __device__ __forceinline__ void begin(unsigned tag) { where = tag; n = 0u; }
     __device__ __forceinline__ bool give_up() {
         if (dead) return true;
         ++n;
         if ((n & 1023u) == 0u) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (n == 1024u) t0 = now;
             if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) dead = true;
-            if (n >= PD_SPIN_LIMIT) {
-                __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (now - t0 > PD_WAIT_LIMIT_TICKS) {
+                if (__hip_atomic_exchange(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    __hip_atomic_store(abort_word + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(abort_word + 2, where, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 dead = true;
             }
         }
@@ -123,6 +134,7 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
     const int wave = __builtin_amdgcn_readfirstlane(wave_v);              // provably uniform -> scalar addressing
     const unsigned lane_bytes = (unsigned)(lq * Bpad + lb) * 32u;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    spin.begin(sg.e1 < nk16 ? sg.tag2 : (sg.e0 < nk16 ? sg.tag1 : sg.tag0));   // (the stage's last, late segment)
 #pragma unroll
     for (int hb = 0; hb < CH + PD_BATCH; hb += PD_BATCH) {
         // batches [0, E0), [E0, E0 + PD_BATCH), ...
@@ -217,6 +229,7 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
 // one quad with a tag wait
 __device__ __forceinline__ f32x4 pd_wait_quad(__amdgpu_buffer_rsrc_t rs, unsigned float_off, unsigned tag, Spin& spin) {
     GQuad g;
+    spin.begin(tag);
     while (true) {
         g = pd_ldg(rs, float_off);
         if (__all(gq_ok(g, tag)) || spin.give_up()) break;
@@ -272,7 +285,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
     const int b0 = bt * 16, Bpad = a.Bpad;
     const int lb = b0 + (lane & 15), lq = lane >> 4;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.region, 0, a.region_bytes, 0x00020000);
-    Spin spin{reinterpret_cast<unsigned*>(a.sync) + 1, 0u, false};
+    Spin spin{reinterpret_cast<unsigned*>(a.sync) + 1, 0u, false, 0u, 0ull};
 #ifdef PD_STAMPS
     spin.st_lds = reinterpret_cast<unsigned long long*>(smem + 4096); spin.stamp_i = 0; spin.stamp_on = false;
 #endif
@@ -523,6 +536,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
                 for (int t0 = 0; t0 < o_n; t0 += PD_THREADS) {
                     const int t = t0 + tid;
                     u32x2 g = {0u, T + 6u};
+                    spin.begin(T + 6u);
                     while (true) {
                         if (t < o_n)
                             g = __builtin_amdgcn_raw_buffer_load_b64(rs, (a.o_e + (unsigned)(b_att * a.T_in + o_lo + t) * 2u) * 4u, 0, 16);

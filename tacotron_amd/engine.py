@@ -5,6 +5,7 @@ PyTorch-ROCm is used for exactly three things: device buffers (`torch.empty(...,
 C-ABI calls (include/taco.h). Mirrors what one `tf.Session` does for the reference
 (synthesizer.py:29-43): holds the restored weights and runs the graph on fed ids."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -67,12 +68,23 @@ class TacoEngine:
             raise TacoError('taco_workspace_bytes rejected B=%d T_in=%d max_iters=%d' % (B, T_in, S))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws = self._empty((need,), torch.uint8)
         return self._ws
+
+    def _empty(self, shape, dtype):
+        """torch.empty on the engine's device, marked as in use on the engine's stream: the caching allocator, which
+        hands freed blocks straight back to the allocating (current) stream, must not recycle a buffer that kernels
+        of this engine's stream may still be writing - a caller that drops an output while the engine runs detached
+        would otherwise let the next allocation (another engine's workspace, say) alias it."""
+        t = torch.empty(*shape, dtype=dtype, device=self.device)
+        t.record_stream(self.stream)
+        return t
 
     def _dev(self, x, dtype):
         t = torch.as_tensor(np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x)
-        return t.to(device=self.device, dtype=dtype).contiguous()
+        t = t.to(device=self.device, dtype=dtype).contiguous()
+        t.record_stream(self.stream)
+        return t
 
     # By default every call is ordered after torch's current stream and torch's current stream after it, so
     # callers can mix engine calls with ordinary torch code. `detached = True` drops both edges: the engine's
@@ -108,7 +120,7 @@ class TacoEngine:
         if lens.shape != (B,):
             raise TacoError('input_lengths must have shape [B]')
         ws = self._workspace(B, T_in, self.hp.max_iters)
-        enc = torch.empty(B, T_in, 2 * self.hp.encoder_gru_num_cells, dtype=torch.float32, device=self.device)
+        enc = self._empty((B, T_in, 2 * self.hp.encoder_gru_num_cells,), torch.float32)
         self._enter()
         self._check(self.lib.taco_encode(self.handle, ids.data_ptr(), lens.data_ptr(), B, T_in, enc.data_ptr(),
                                          ws.data_ptr(), ws.numel(), self._s))
@@ -121,9 +133,10 @@ class TacoEngine:
         S = int(max_iters or self.hp.max_iters)
         r, M = self.hp.outputs_per_step, self.hp.num_mels
         ws = self._workspace(B, T_in, S)
-        mel = torch.empty(B, S * r, M, dtype=torch.float32, device=self.device)
-        align = torch.empty(B, T_in, S, dtype=torch.float32, device=self.device)
+        mel = self._empty((B, S * r, M,), torch.float32)
+        align = self._empty((B, T_in, S,), torch.float32)
         steps = torch.zeros(1, dtype=torch.int32, device=self.device)
+        steps.record_stream(self.stream)
         keep = None
         if dropout_keep is not None:
             keep = self._dev(dropout_keep, torch.float32)
@@ -142,7 +155,7 @@ class TacoEngine:
         B, T, _ = mel.shape
         S = -(-T // self.hp.outputs_per_step)
         ws = self._workspace(B, 1, S)
-        lin = torch.empty(B, T, self.hp.num_freq, dtype=torch.float32, device=self.device)
+        lin = self._empty((B, T, self.hp.num_freq,), torch.float32)
         self._enter()
         self._check(self.lib.taco_postnet(self.handle, mel.data_ptr(), B, T, lin.data_ptr(), ws.data_ptr(),
                                           ws.numel(), self._s))
@@ -159,7 +172,7 @@ class TacoEngine:
         _, hop, win = self.hp.stft_params()
         S = -(-T // self.hp.outputs_per_step)
         ws = self._workspace(B, 1, S)
-        wav = torch.empty(B, (T - 1) * hop + win, dtype=torch.float32, device=self.device)
+        wav = self._empty((B, (T - 1) * hop + win,), torch.float32)
         self._enter()
         self._check(self.lib.taco_griffin_lim(self.handle, linear.data_ptr(), B, T, iters, wav.data_ptr(),
                                               ws.data_ptr(), ws.numel(), self._s))
@@ -182,7 +195,7 @@ class TacoEngine:
         def buf(name, shape, dtype=torch.float32):
             t = o.get(name)
             if t is None or tuple(t.shape) != tuple(shape):
-                t = torch.empty(*shape, dtype=dtype, device=self.device)
+                t = self._empty(tuple(shape), dtype)
                 o[name] = t
             return t
         enc = buf('enc_out', (B, T_in, 2 * self.hp.encoder_gru_num_cells))

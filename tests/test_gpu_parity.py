@@ -272,3 +272,40 @@ def test_synthesize_end_to_end(engine, hp, weights):
     wav_ref = O.spectrogram_tensorflow_inv(ref['linear'], hp, iters=2)
     assert _np(o['wav']).shape == wav_ref.shape
     assert np.linalg.norm(_np(o['wav']) - wav_ref) / np.linalg.norm(wav_ref) < 1e-3
+
+
+def test_persistent_decode_under_uneven_load(engine, hp, weights):
+    """The persistent decoder's inter-workgroup hand-offs must not depend on an idle chip: the same decode, run
+    while two other engines keep the other CUs busy with GEMM-heavy post-nets and a second persistent decode on their
+    own streams, is bit-identical to the run alone (and its bounded waits do not time out)."""
+    import torch
+    from tacotron_amd.engine import TacoEngine
+    rng = np.random.default_rng(11)
+    enc = torch.from_numpy(rng.standard_normal((24, 150, 256)).astype(np.float32) * 0.5).cuda()
+    mel_load = torch.from_numpy(rng.standard_normal((16, 400, hp.num_mels)).astype(np.float32)).cuda()
+    engine.set_decode_graph(2)
+    m0, a0, _ = engine.decode(enc, max_iters=60)
+    torch.cuda.synchronize()
+    engine.decode_status()
+    m0, a0 = m0.clone(), a0.clone()
+    others = [TacoEngine(weights, hp, device=0) for _ in range(2)]
+    try:
+        for e in others + [engine]:
+            e.detached = True
+        torch.cuda.synchronize()
+        for rep in range(3):
+            for _ in range(4):
+                others[0].postnet(mel_load)
+            others[1].decode(enc[:7], max_iters=40)
+            m1, a1, _ = engine.decode(enc, max_iters=60)
+            for _ in range(4):
+                others[0].postnet(mel_load)
+            torch.cuda.synchronize()
+            engine.decode_status()
+            others[1].decode_status()
+            assert torch.equal(m1, m0) and torch.equal(a1, a0), 'rep %d' % rep
+    finally:
+        engine.detached = False
+        torch.cuda.synchronize()
+        for e in others:
+            e.close()
