@@ -23,11 +23,11 @@ for B in [int(a) for a in sys.argv[1:]] or [32]:
     lin = eng.postnet(mel)
     t_enc = timeit(lambda: eng.encode(ids_d, lens_d))
     t_dec = timeit(lambda: eng.decode(enc))
-    eng.set_decode_graph(False); t_dec_e = timeit(lambda: eng.decode(enc)); eng.set_decode_graph(True)
+    eng.set_decode_graph(1); t_dec_g = timeit(lambda: eng.decode(enc)); eng.set_decode_graph(0); t_dec_e = timeit(lambda: eng.decode(enc)); eng.set_decode_graph(2)
     t_post = timeit(lambda: eng.postnet(mel))
     t_gl = timeit(lambda: eng.griffin_lim(lin[:, :, :]), n=2)
     out = {}
     t_all = timeit(lambda: eng.synthesize(ids_d, lens_d, out=out))
-    print('B=%d: encode %.2f ms | decode graph %.2f ms (%.1f us/step) eager %.2f ms | postnet %.2f ms | GL60 %.1f ms | synthesize %.2f ms -> %.0f frames/s'
-          % (B, t_enc, t_dec, t_dec * 1e3 / 200, t_dec_e, t_post, t_gl, t_all, B * 1000 / t_all * 1e3), flush=True)
+    print('B=%d: encode %.2f ms | decode persistent %.2f ms (%.1f us/step) graph %.2f eager %.2f ms | postnet %.2f ms | GL60 %.1f ms | synthesize %.2f ms -> %.0f frames/s'
+          % (B, t_enc, t_dec, t_dec * 1e3 / 200, t_dec_g, t_dec_e, t_post, t_gl, t_all, B * 1000 / t_all * 1e3), flush=True)
 eng.close()
