@@ -2,9 +2,13 @@
 // host emulation test (tests/host/fft_host_test.cpp): plain C++ so the index maths can be
 // checked on the CPU where there is no GPU.
 //
-// A real 2048-point transform is computed as a 1024-point complex Stockham radix-4 FFT of the
-// even/odd-packed signal z[m] = x[2m] + i x[2m+1] plus a split step; 256 "threads" each own
-// one radix-4 butterfly per pass (5 passes, ping-pong buffers).
+// A real 2048-point transform is computed as a 1024-point complex FFT of the even/odd-packed
+// signal z[m] = x[2m] + i x[2m+1] plus a split step. The complex FFT is done by ONE 64-lane wave
+// with 16 points per lane in registers, as a three-pass mixed-radix Stockham transform
+// (16 x 16 x 4): lane l is butterfly l of the two radix-16 passes and butterflies l, l+64, l+128,
+// l+192 of the radix-4 pass. Every pass reads x[l + 64 i] (contiguous over lanes) and writes
+// y[(t - k) R + k + p i'] (k = t mod p, p = product of the radices done so far), exchanged through a
+// wave-private LDS buffer that is padded by one element per 16 (conflict-free strides).
 #pragma once
 
 #if defined(__HIPCC__)
@@ -23,37 +27,146 @@ TACO_HD cplx csub(cplx a, cplx b) { return {a.x - b.x, a.y - b.y}; }
 TACO_HD cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 TACO_HD cplx cconj(cplx a) { return {a.x, -a.y}; }
 
-constexpr int FFT_N = 1024;      // complex length
-constexpr int FFT_T = 256;       // butterflies ("threads") per pass
-constexpr int FFT_PASSES = 5;    // 4^5 = 1024
+constexpr int FFT_N = 1024;                 // complex length
+constexpr int FFT_LANES = 64;               // one wave
+constexpr int FFT_PER_LANE = 16;
+constexpr int FFT_LDS = FFT_N + FFT_N / 16; // padded exchange buffer, complex elements
+TACO_HD int fft_pad(int j) { return j + (j >> 4); }
 
-// One radix-4 Stockham butterfly. t in [0,256); p = 4^pass = size of the sub-transforms done so
-// far. W[j] = exp(-2*pi*i*j/2048), j < 2048. INV uses conjugate twiddles (no 1/N scaling).
+// 4-point DFT in place, natural order. INV: conjugate kernel (no scaling).
 template <bool INV>
-TACO_HD void fft1024_radix4(const cplx* x, cplx* y, int t, int p, const cplx* W) {
-    const int k = t & (p - 1);
-    const int step = 512 / p;    // twiddle exp(-+2*pi*i*k*m/(4p)) = W[k*m*(2048/(4p))]
-    cplx u0 = x[t];
-    cplx u1 = x[t + FFT_T];
-    cplx u2 = x[t + 2 * FFT_T];
-    cplx u3 = x[t + 3 * FFT_T];
-    if (p > 1) {
-        cplx w1 = W[k * step], w2 = W[2 * k * step], w3 = W[3 * k * step];
-        if (INV) { w1 = cconj(w1); w2 = cconj(w2); w3 = cconj(w3); }
-        u1 = cmul(u1, w1);
-        u2 = cmul(u2, w2);
-        u3 = cmul(u3, w3);
-    }
-    const cplx v0 = cadd(u0, u2);
-    const cplx v1 = csub(u0, u2);
-    const cplx v2 = cadd(u1, u3);
-    const cplx d = csub(u1, u3);
+TACO_HD void dft4(cplx& a0, cplx& a1, cplx& a2, cplx& a3) {
+    const cplx v0 = cadd(a0, a2);
+    const cplx v1 = csub(a0, a2);
+    const cplx v2 = cadd(a1, a3);
+    const cplx d = csub(a1, a3);
     const cplx v3 = INV ? cplx{-d.y, d.x} : cplx{d.y, -d.x};   // d * (+i) : d * (-i)
-    const int j = ((t - k) << 2) + k;
-    y[j] = cadd(v0, v2);
-    y[j + p] = cadd(v1, v3);
-    y[j + 2 * p] = csub(v0, v2);
-    y[j + 3 * p] = csub(v1, v3);
+    a0 = cadd(v0, v2);
+    a1 = cadd(v1, v3);
+    a2 = csub(v0, v2);
+    a3 = csub(v1, v3);
+}
+
+// w16^n = exp(-2 pi i n / 16) for the products n = a2 * c1 that occur (0,1,2,3,4,6,9)
+template <bool INV>
+TACO_HD cplx w16(int n) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, C2 = 0.70710678118654752f;
+    cplx w;
+    switch (n) {
+        case 1: w = {C1, -S1}; break;
+        case 2: w = {C2, -C2}; break;
+        case 3: w = {S1, -C1}; break;
+        case 4: w = {0.f, -1.f}; break;
+        case 6: w = {-C2, -C2}; break;
+        case 9: w = {-C1, S1}; break;
+        default: w = {1.f, 0.f}; break;
+    }
+    return INV ? cconj(w) : w;
+}
+
+// 16-point DFT in place, natural order in and out (index a = 4 a1 + a2, c = c1 + 4 c2).
+template <bool INV>
+TACO_HD void dft16(cplx (&v)[16]) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int a2 = 0; a2 < 4; ++a2) dft4<INV>(v[a2], v[4 + a2], v[8 + a2], v[12 + a2]);   // -> v[4 c1 + a2]
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int c1 = 1; c1 < 4; ++c1)
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int a2 = 1; a2 < 4; ++a2) v[4 * c1 + a2] = cmul(v[4 * c1 + a2], w16<INV>(a2 * c1));
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int c1 = 0; c1 < 4; ++c1) dft4<INV>(v[4 * c1], v[4 * c1 + 1], v[4 * c1 + 2], v[4 * c1 + 3]);   // -> v[4 c1 + c2]
+    cplx o[16];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int c1 = 0; c1 < 4; ++c1)
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int c2 = 0; c2 < 4; ++c2) o[c1 + 4 * c2] = v[4 * c1 + c2];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int c = 0; c < 16; ++c) v[c] = o[c];
+}
+
+// Twiddle tables of passes 2 and 3, built once per workgroup (in LDS on the device) from
+// W[j] = exp(-2 pi i j / 2048), j < 2048, laid out so that the 64 lanes read consecutive entries:
+//   T2[(i-1)*16 + k]  = w256^(k i),   k < 16, i = 1..15   (pass 2: p = 16, radix 16, k = lane & 15)
+//   T3[(i-1)*256 + t] = w1024^(t i),  t < 256, i = 1..3   (pass 3: p = 256, radix 4, t = lane + 64 q)
+constexpr int FFT_T2 = 15 * 16, FFT_T3 = 3 * 256, FFT_TW = FFT_T2 + FFT_T3;
+TACO_HD cplx fft_tw_entry(int e, const cplx* W) {
+    if (e < FFT_T2) { const int i = e / 16 + 1, k = e % 16; return W[8 * k * i]; }
+    e -= FFT_T2;
+    const int i = e / 256 + 1, t = e % 256;
+    return W[2 * t * i];
+}
+
+// ---- the passes, split into the part before and after the exchange so that a host emulation can run
+// "all lanes load, then all lanes store" like the wave does.
+// every pass starts from v[i] = x[lane + 64 i]
+TACO_HD void fft_load(cplx (&v)[16], const cplx* lds, int lane) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 16; ++i) v[i] = lds[fft_pad(lane + 64 * i)];
+}
+TACO_HD void fft_store_natural(const cplx (&v)[16], cplx* lds, int lane) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 16; ++i) lds[fft_pad(lane + 64 * i)] = v[i];
+}
+// pass 1 (p = 1): y[16 t + c]
+template <bool INV>
+TACO_HD void fft_pass1(cplx (&v)[16], cplx* lds, int lane) {
+    dft16<INV>(v);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int c = 0; c < 16; ++c) lds[fft_pad(16 * lane + c)] = v[c];
+}
+// pass 2 (p = 16): twiddle, DFT16, y[(t - k) 16 + k + 16 c]; v must hold x[lane + 64 i]
+template <bool INV>
+TACO_HD void fft_pass2(cplx (&v)[16], cplx* lds, int lane, const cplx* T2) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 1; i < 16; ++i) {
+        const cplx w = T2[(i - 1) * 16 + (lane & 15)];
+        v[i] = cmul(v[i], INV ? cconj(w) : w);
+    }
+    dft16<INV>(v);
+    const int base = (lane >> 4) * 256 + (lane & 15);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int c = 0; c < 16; ++c) lds[fft_pad(base + 16 * c)] = v[c];
+}
+// pass 3 (p = 256, radix 4): in registers; on return v[m] = X[lane + 64 m] (natural order)
+template <bool INV>
+TACO_HD void fft_pass3(cplx (&v)[16], int lane, const cplx* T3) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int q = 0; q < 4; ++q) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int i = 1; i < 4; ++i) {
+            const cplx w = T3[(i - 1) * 256 + lane + 64 * q];
+            v[q + 4 * i] = cmul(v[q + 4 * i], INV ? cconj(w) : w);
+        }
+        dft4<INV>(v[q], v[q + 4], v[q + 8], v[q + 12]);
+    }
 }
 
 // Split step of the real transform for the bin pair (k, 1024-k), 1 <= k <= 511:
@@ -77,7 +190,6 @@ TACO_HD void irfft_merge(cplx Yk, cplx Yn, cplx Wk, cplx& Zk, cplx& Zn) {
     const cplx O = cmul(D, cconj(Wk));
     const cplx iO = {-O.y, O.x};
     Zk = cadd(E, iO);
-    // Z'[N-k] = conj(E) + i conj(O) = conj(E - iO)... i*conj(O) = conj(-i*O) => conj(E) - conj(iO)
     Zn = cconj(csub(E, iO));
 }
 

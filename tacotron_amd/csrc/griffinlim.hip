@@ -4,14 +4,15 @@
 // with stft = frame(1200, hop 300, no padding) * periodicHann -> rfft(2048, zero-padded at the
 // end) and istft = irfft(2048)[:1200] * periodicHann -> overlap-add (no window-sum division).
 //
-// One kernel per iteration (gl_iter): a 256-thread workgroup owns one frame at a time -
-// it rebuilds the frame's 1200 input samples by overlap-adding the <=4 frames of the previous
-// iteration that cover them (fixed order, so results are reproducible), windows, runs the
-// 2048-point real FFT in LDS (1024-point complex radix-4 Stockham + split), re-phases against
-// the target magnitude, runs the inverse and writes its windowed 1200 output samples.  The
-// signal y itself is never materialised between iterations; gl_ola builds it once at the end.
-// HBM/L2 traffic per frame and iteration: 4.1 KB magnitudes + <=19.2 KB frame reads + 4.8 KB
-// frame writes.
+// One kernel per iteration (gl_iter). A 256-thread workgroup owns a run of consecutive frames of one utterance:
+// it first rebuilds the time samples those frames cover by overlap-adding the frames of the previous iteration
+// (each sample once, fixed order: reproducible; the signal y itself is never materialised in HBM between
+// iterations, gl_ola builds it once at the end) into LDS; then each of its four waves takes frames of the run and
+// does the whole frame on its own, 16 complex points per lane in registers: window -> 2048-point real FFT as a
+// 1024-point complex three-pass (16 x 16 x 4) transform + split (fft_core.h) -> re-phase against the target magnitude
+// -> merge -> inverse -> window -> store. The waves never meet at a barrier inside the frame loop; a wave's passes
+// exchange data through its private, padded LDS buffer.
+// HBM/L2 traffic per frame and iteration: 4.1 KB magnitudes + ~5.7 KB frame reads + 4.8 KB frame writes.
 #include "kernels.h"
 #include "fft_core.h"
 
@@ -36,116 +37,156 @@ void launch_gl_mag(const float* lin, float* mag, size_t n, float min_db, float r
     if (tm) tm->end(KK_GL_MAG, s);
 }
 
-constexpr int GL_THREADS = FFT_T;   // 256
+constexpr int GL_THREADS = 256;
+constexpr int GL_WAVES = 4;
+constexpr int GL_RUN = 16;          // consecutive frames per workgroup (upper bound; the launcher may lower it)
 
-__global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(const float* __restrict__ frames_in,
+// LDS: [y segment: (run-1)*hop + win floats][window: win floats][twiddle tables: FFT_TW cplx][4 x FFT_LDS cplx]
+__global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __restrict__ frames_in,
                                                              const float* __restrict__ mag,
                                                              float* __restrict__ frames_out,
                                                              const float2* __restrict__ twiddle,
                                                              const float* __restrict__ window, int B, int T, int hop,
-                                                             int win, int nbins, int first) {
-    __shared__ __attribute__((aligned(16))) cplx W[2 * FFT_N];
-    __shared__ __attribute__((aligned(16))) cplx buf[2][FFT_N];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 2 * FFT_N; i += GL_THREADS) {
-        const float2 w = twiddle[i];
-        W[i] = {w.x, w.y};
-    }
-    const int half_win = win >> 1;                // complex samples carrying data
-    const int nover = (win + hop - 1) / hop;      // frames covering one sample (4)
-    const long nframes = (long)B * T;
+                                                             int win, int nbins, int first, int run, int runs_per_utt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gl_smem[];
+    const int seg_cap = (run - 1) * hop + win;
+    float* yseg = reinterpret_cast<float*>(gl_smem);
+    float* win_s = yseg + ((seg_cap + 3) & ~3);
+    cplx* tw_s = reinterpret_cast<cplx*>(win_s + ((win + 3) & ~3));
+    const cplx* T2 = tw_s;
+    const cplx* T3 = tw_s + FFT_T2;
+    cplx* fft_s = tw_s + FFT_TW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    cplx* lds = fft_s + wave * FFT_LDS;
+    const cplx* Wt = reinterpret_cast<const cplx*>(twiddle);
 
-    for (long f = blockIdx.x; f < nframes; f += gridDim.x) {
-        const int m = (int)(f % T);
-        const long fb = f - m;                    // first frame of this utterance
-        __syncthreads();                          // W loaded / previous frame's buffers free
-        int cur = 0;
+    const int b = blockIdx.x / runs_per_utt;
+    const int m0 = (blockIdx.x - b * runs_per_utt) * run;
+    const int nfr = min(run, T - m0);
+    const long fb = (long)b * T;                   // first frame of this utterance
+    const int half_win = win >> 1;                 // complex samples carrying data
+    const int nover = (win + hop - 1) / hop;       // frames covering one sample (4)
+
+    for (int i = tid; i < win; i += GL_THREADS) win_s[i] = window[i];
+    for (int e = tid; e < FFT_TW; e += GL_THREADS) tw_s[e] = fft_tw_entry(e, Wt);
+    if (!first) {
+        // ---- the samples the run covers: y[hop*m0 + i] = sum of the covering frames of the previous iteration
+        const int seg = (nfr - 1) * hop + win;
+        for (int i = 2 * tid; i < seg; i += 2 * GL_THREADS) {
+            const int g = hop * m0 + i;
+            const int q = g / hop;
+            const int mhi = min(T - 1, q);
+            const int mlo = max(0, q - (nover - 1));
+            float sx = 0.f, sy = 0.f;
+            for (int m2 = mlo; m2 <= mhi; ++m2) {
+                const int off = g - hop * m2;
+                if (off < win) {
+                    const float2 v = *reinterpret_cast<const float2*>(frames_in + (fb + m2) * win + off);
+                    sx += v.x;
+                    sy += v.y;
+                }
+            }
+            *reinterpret_cast<float2*>(yseg + i) = make_float2(sx, sy);
+        }
+    }
+    __syncthreads();
+
+    for (int fi = wave; fi < nfr; fi += GL_WAVES) {
+        const long f = fb + m0 + fi;
+        const float* mg = mag + f * nbins;
+        cplx v[16];
         if (!first) {
-            // ---- analysis input: y[hop*m + n] = sum of covering frames, * window, packed even/odd
-            for (int c = tid; c < FFT_N; c += GL_THREADS) {
+            // ---- analysis: window, even/odd packing z[c] = (y[2c], y[2c+1]), c = lane + 64 i
+            const float* ys = yseg + hop * fi;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = lane + 64 * i;
                 cplx z = {0.f, 0.f};
                 if (c < half_win) {
-                    const int n = 2 * c;
-                    const int g = hop * m + n;
-                    const int mhi = min(T - 1, g / hop);
-                    const int mlo = max(0, g / hop - (nover - 1));
-                    float sx = 0.f, sy = 0.f;
-                    for (int m2 = mlo; m2 <= mhi; ++m2) {
-                        const int off = g - hop * m2;
-                        if (off + 1 < win + 1 && off < win) {
-                            const float2 v = *reinterpret_cast<const float2*>(frames_in + (fb + m2) * win + off);
-                            sx += v.x;
-                            sy += v.y;
-                        }
-                    }
-                    z = {sx * window[n], sy * window[n + 1]};
+                    const float2 sv = *reinterpret_cast<const float2*>(ys + 2 * c);
+                    const float2 wv = *reinterpret_cast<const float2*>(win_s + 2 * c);
+                    z = {sv.x * wv.x, sv.y * wv.y};
                 }
-                buf[0][c] = z;
+                v[i] = z;
             }
-            __syncthreads();
-            // ---- forward FFT-1024
+            fft_pass1<false>(v, lds, lane);
+            __builtin_amdgcn_wave_barrier();
+            fft_load(v, lds, lane);
+            __builtin_amdgcn_wave_barrier();
+            fft_pass2<false>(v, lds, lane, T2);
+            __builtin_amdgcn_wave_barrier();
+            fft_load(v, lds, lane);
+            __builtin_amdgcn_wave_barrier();
+            fft_pass3<false>(v, lane, T3);                // v[m] = Z[lane + 64 m]
+            // upper half to LDS: the partner bins 1024 - k of the other lanes
 #pragma unroll
-            for (int ps = 0, p = 1; ps < FFT_PASSES; ++ps, p <<= 2) {
-                fft1024_radix4<false>(buf[cur], buf[cur ^ 1], tid, p, W);
-                cur ^= 1;
-                __syncthreads();
-            }
+            for (int i = 8; i < 16; ++i) lds[fft_pad(lane + 64 * i)] = v[i];
+            __builtin_amdgcn_wave_barrier();
         }
-        // ---- split -> re-phase against mag -> merge, in place on the bin pairs (k, 1024-k)
-        {
-            cplx* Z = buf[cur];
-            const float* mg = mag + f * nbins;
-            for (int k = tid; k < FFT_N / 2; k += GL_THREADS) {
-                if (k == 0) {
-                    // bins 0 and 1024 are real: X0 = Re Z0 + Im Z0, X1024 = Re Z0 - Im Z0
-                    float y0, yn;
-                    if (first) { y0 = mg[0]; yn = mg[FFT_N]; }
-                    else {
-                        const cplx z0 = Z[0];
-                        y0 = gl_rephase({z0.x + z0.y, 0.f}, mg[0]).x;
-                        yn = gl_rephase({z0.x - z0.y, 0.f}, mg[FFT_N]).x;
-                    }
-                    Z[0] = {0.5f * (y0 + yn), 0.5f * (y0 - yn)};
-                    // bin 512 pairs with itself: X512 = conj(Z512); Z'512 = conj(Y512)
-                    cplx ym;
-                    if (first) ym = {mg[FFT_N / 2], 0.f};
-                    else ym = gl_rephase(cconj(Z[FFT_N / 2]), mg[FFT_N / 2]);
-                    Z[FFT_N / 2] = cconj(ym);
-                } else {
-                    const cplx Wk = W[k];
-                    cplx Yk, Yn;
-                    if (first) { Yk = {mg[k], 0.f}; Yn = {mg[FFT_N - k], 0.f}; }
-                    else {
-                        cplx Xk, Xn;
-                        rfft_split(Z[k], Z[FFT_N - k], Wk, Xk, Xn);
-                        Yk = gl_rephase(Xk, mg[k]);
-                        Yn = gl_rephase(Xn, mg[FFT_N - k]);
-                    }
-                    cplx Zk, Zn;
-                    irfft_merge(Yk, Yn, Wk, Zk, Zn);
-                    Z[k] = Zk;
-                    Z[FFT_N - k] = Zn;
+        // ---- split -> re-phase against mag -> merge on the bin pairs (k, 1024 - k), k = lane + 64 j
+        float mk[8], mn[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = lane + 64 * j;
+            mk[j] = mg[k];
+            mn[j] = mg[FFT_N - k];     // (k = 0: bin 1024)
+        }
+        const float m512 = mg[FFT_N / 2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = lane + 64 * j;
+            if (k == 0) {
+                // bins 0 and 1024 are real: X0 = Re Z0 + Im Z0, X1024 = Re Z0 - Im Z0
+                float y0, yn;
+                if (first) { y0 = mk[0]; yn = mn[0]; }
+                else {
+                    y0 = gl_rephase({v[0].x + v[0].y, 0.f}, mk[0]).x;
+                    yn = gl_rephase({v[0].x - v[0].y, 0.f}, mn[0]).x;
                 }
+                v[0] = {0.5f * (y0 + yn), 0.5f * (y0 - yn)};
+                // bin 512 pairs with itself: X512 = conj(Z512); Z'512 = conj(Y512)
+                cplx ym;
+                if (first) ym = {m512, 0.f};
+                else ym = gl_rephase(cconj(v[8]), m512);
+                lds[fft_pad(FFT_N / 2)] = cconj(ym);
+            } else {
+                const cplx Wk = Wt[k];
+                cplx Yk, Yn;
+                if (first) { Yk = {mk[j], 0.f}; Yn = {mn[j], 0.f}; }
+                else {
+                    cplx Xk, Xn;
+                    rfft_split(v[j], lds[fft_pad(FFT_N - k)], Wk, Xk, Xn);
+                    Yk = gl_rephase(Xk, mk[j]);
+                    Yn = gl_rephase(Xn, mn[j]);
+                }
+                cplx Zk, Zn;
+                irfft_merge(Yk, Yn, Wk, Zk, Zn);
+                v[j] = Zk;
+                lds[fft_pad(FFT_N - k)] = Zn;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 8; i < 16; ++i) v[i] = lds[fft_pad(lane + 64 * i)];
+        __builtin_amdgcn_wave_barrier();
         // ---- inverse FFT-1024
-#pragma unroll
-        for (int ps = 0, p = 1; ps < FFT_PASSES; ++ps, p <<= 2) {
-            fft1024_radix4<true>(buf[cur], buf[cur ^ 1], tid, p, W);
-            cur ^= 1;
-            __syncthreads();
-        }
+        fft_pass1<true>(v, lds, lane);
+        __builtin_amdgcn_wave_barrier();
+        fft_load(v, lds, lane);
+        __builtin_amdgcn_wave_barrier();
+        fft_pass2<true>(v, lds, lane, T2);
+        __builtin_amdgcn_wave_barrier();
+        fft_load(v, lds, lane);
+        __builtin_amdgcn_wave_barrier();
+        fft_pass3<true>(v, lane, T3);
         // ---- synthesis window, first `win` samples, 1/1024 scaling
-        {
-            const cplx* z = buf[cur];
-            const float sc = 1.f / FFT_N;
-            for (int c = tid; c < half_win; c += GL_THREADS) {
-                const cplx v = z[c];
-                float2 o;
-                o.x = v.x * sc * window[2 * c];
-                o.y = v.y * sc * window[2 * c + 1];
-                *reinterpret_cast<float2*>(frames_out + f * win + 2 * c) = o;
+        const float sc = 1.f / FFT_N;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = lane + 64 * i;
+            if (c < half_win) {
+                const float2 wv = *reinterpret_cast<const float2*>(win_s + 2 * c);
+                *reinterpret_cast<float2*>(frames_out + f * win + 2 * c) = make_float2(v[i].x * sc * wv.x, v[i].y * sc * wv.y);
             }
         }
     }
@@ -154,10 +195,21 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(const float* __rest
 void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, float* frames_out, int B, int T,
                     int first, hipStream_t s, Timing* tm) {
     if (tm) tm->begin(KK_GL_ITER, s);
-    const long nframes = (long)B * T;
-    const int blocks = (int)std::min<long>(nframes, 256 * 5);
-    hipLaunchKernelGGL(gl_iter_kernel, dim3(blocks), dim3(GL_THREADS), 0, s, frames_in, mag, frames_out,
-                       (const float2*)p.twiddle, p.window, B, T, p.hop, p.win, p.nbins, first);
+    // frames per workgroup: as many as keep the y segment within ~24 KB of LDS (2 workgroups per CU and more)
+    int run = GL_RUN;
+    while (run > 1 && ((size_t)(run - 1) * p.hop + p.win) * 4 > 24 * 1024) --run;
+    const int runs_per_utt = (T + run - 1) / run;
+    const size_t lds = (size_t)((((run - 1) * p.hop + p.win + 3) & ~3) + ((p.win + 3) & ~3)) * 4 +
+                       (size_t)(FFT_TW + GL_WAVES * FFT_LDS) * sizeof(cplx);
+    static bool attr_set = false;
+    if (!attr_set) {   // more than the default 64 KB of dynamic LDS
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gl_iter_kernel, dim3((unsigned)(B * runs_per_utt)), dim3(GL_THREADS), lds, s, frames_in, mag,
+                       frames_out, (const float2*)p.twiddle, p.window, B, T, p.hop, p.win, p.nbins, first, run,
+                       runs_per_utt);
     if (tm) tm->end(KK_GL_ITER, s);
 }
 

@@ -1,5 +1,6 @@
 // Host emulation of the Griffin-Lim kernel's FFT path (tacotron_amd/csrc/fft_core.h): runs the
-// same butterflies "thread by thread" and checks them against a direct O(N^2) DFT in double.
+// same three passes "lane by lane" (all lanes up to an exchange, then all lanes past it, as the wave
+// does) and checks them against a direct O(N^2) DFT in double.
 // Prints "max_err_fwd max_err_inv max_err_roundtrip"; exit code 0 if all are small.
 #include <cmath>
 #include <cstdio>
@@ -24,13 +25,26 @@ int main() {
         Xr[k] = sr; Xi[k] = si;
     }
     // emulated forward
+    std::vector<cplx> lds(FFT_LDS);
+    std::vector<cplx> tw(FFT_TW);
+    for (int e = 0; e < FFT_TW; ++e) tw[e] = fft_tw_entry(e, W.data());
+    const cplx* T2 = tw.data();
+    const cplx* T3 = tw.data() + FFT_T2;
+    static cplx v[FFT_LANES][16];
+    auto fft = [&](bool inv) {   // in: v[l][i] = x[l + 64 i]; out: v[l][m] = X[l + 64 m]
+        for (int l = 0; l < FFT_LANES; ++l) { if (inv) fft_pass1<true>(v[l], lds.data(), l); else fft_pass1<false>(v[l], lds.data(), l); }
+        for (int l = 0; l < FFT_LANES; ++l) fft_load(v[l], lds.data(), l);
+        for (int l = 0; l < FFT_LANES; ++l) { if (inv) fft_pass2<true>(v[l], lds.data(), l, T2); else fft_pass2<false>(v[l], lds.data(), l, T2); }
+        for (int l = 0; l < FFT_LANES; ++l) fft_load(v[l], lds.data(), l);
+        for (int l = 0; l < FFT_LANES; ++l) { if (inv) fft_pass3<true>(v[l], l, T3); else fft_pass3<false>(v[l], l, T3); }
+    };
+    for (int l = 0; l < FFT_LANES; ++l)
+        for (int i = 0; i < 16; ++i) v[l][i] = {(float)x[2 * (l + 64 * i)], (float)x[2 * (l + 64 * i) + 1]};
+    fft(false);
     std::vector<cplx> buf[2] = {std::vector<cplx>(FFT_N), std::vector<cplx>(FFT_N)};
-    for (int c = 0; c < FFT_N; ++c) buf[0][c] = {(float)x[2 * c], (float)x[2 * c + 1]};
     int cur = 0;
-    for (int ps = 0, p = 1; ps < FFT_PASSES; ++ps, p <<= 2) {
-        for (int t = 0; t < FFT_T; ++t) fft1024_radix4<false>(buf[cur].data(), buf[cur ^ 1].data(), t, p, W.data());
-        cur ^= 1;
-    }
+    for (int l = 0; l < FFT_LANES; ++l)
+        for (int m = 0; m < 16; ++m) buf[cur][l + 64 * m] = v[l][m];
     std::vector<cplx> X(NB);
     {
         cplx* Z = buf[cur].data();
@@ -61,10 +75,11 @@ int main() {
         Z[FFT_N / 2] = cconj(Y[FFT_N / 2]);
         for (int k = 1; k < FFT_N / 2; ++k) irfft_merge(Y[k], Y[FFT_N - k], W[k], Z[k], Z[FFT_N - k]);
     }
-    for (int ps = 0, p = 1; ps < FFT_PASSES; ++ps, p <<= 2) {
-        for (int t = 0; t < FFT_T; ++t) fft1024_radix4<true>(buf[cur].data(), buf[cur ^ 1].data(), t, p, W.data());
-        cur ^= 1;
-    }
+    for (int l = 0; l < FFT_LANES; ++l)
+        for (int i = 0; i < 16; ++i) v[l][i] = buf[0][l + 64 * i];
+    fft(true);
+    for (int l = 0; l < FFT_LANES; ++l)
+        for (int m = 0; m < 16; ++m) buf[cur][l + 64 * m] = v[l][m];
     double einv = 0, yscale = 0;
     for (int c = 0; c < FFT_N; ++c) {
         einv = fmax(einv, fabs(buf[cur][c].x / FFT_N - yr[2 * c]));
