@@ -41,7 +41,7 @@ constexpr int GL_THREADS = 256;
 constexpr int GL_WAVES = 4;
 constexpr int GL_RUN = 16;          // consecutive frames per workgroup (upper bound; the launcher may lower it)
 
-// LDS: [y segment: (run-1)*hop + win floats][window: win floats][twiddle tables: FFT_TW cplx][4 x FFT_LDS cplx]
+// LDS: [y segment: (run-1)*hop + win floats][window: win floats][twiddle tables: FFT_TW + 512 cplx][4 x FFT_LDS cplx]
 __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __restrict__ frames_in,
                                                              const float* __restrict__ mag,
                                                              float* __restrict__ frames_out,
@@ -55,7 +55,8 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __r
     cplx* tw_s = reinterpret_cast<cplx*>(win_s + ((win + 3) & ~3));
     const cplx* T2 = tw_s;
     const cplx* T3 = tw_s + FFT_T2;
-    cplx* fft_s = tw_s + FFT_TW;
+    cplx* wk_s = tw_s + FFT_TW;            // W[k], k < 512: twiddles of the split / merge step
+    cplx* fft_s = wk_s + FFT_N / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     cplx* lds = fft_s + wave * FFT_LDS;
     const cplx* Wt = reinterpret_cast<const cplx*>(twiddle);
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __r
 
     for (int i = tid; i < win; i += GL_THREADS) win_s[i] = window[i];
     for (int e = tid; e < FFT_TW; e += GL_THREADS) tw_s[e] = fft_tw_entry(e, Wt);
+    for (int e = tid; e < FFT_N / 2; e += GL_THREADS) wk_s[e] = Wt[e];
     if (!first) {
         // ---- the samples the run covers: y[hop*m0 + i] = sum of the covering frames of the previous iteration
         const int seg = (nfr - 1) * hop + win;
@@ -94,6 +96,15 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __r
     for (int fi = wave; fi < nfr; fi += GL_WAVES) {
         const long f = fb + m0 + fi;
         const float* mg = mag + f * nbins;
+        // target magnitudes of this lane's bin pairs (k, 1024 - k), k = lane + 64 j: in flight under the forward FFT
+        float mk[8], mn[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = lane + 64 * j;
+            mk[j] = mg[k];
+            mn[j] = mg[FFT_N - k];     // (k = 0: bin 1024)
+        }
+        const float m512 = mg[FFT_N / 2];
         cplx v[16];
         if (!first) {
             // ---- analysis: window, even/odd packing z[c] = (y[2c], y[2c+1]), c = lane + 64 i
@@ -124,14 +135,6 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __r
             __builtin_amdgcn_wave_barrier();
         }
         // ---- split -> re-phase against mag -> merge on the bin pairs (k, 1024 - k), k = lane + 64 j
-        float mk[8], mn[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = lane + 64 * j;
-            mk[j] = mg[k];
-            mn[j] = mg[FFT_N - k];     // (k = 0: bin 1024)
-        }
-        const float m512 = mg[FFT_N / 2];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = lane + 64 * j;
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __r
                 else ym = gl_rephase(cconj(v[8]), m512);
                 lds[fft_pad(FFT_N / 2)] = cconj(ym);
             } else {
-                const cplx Wk = Wt[k];
+                const cplx Wk = wk_s[k];
                 cplx Yk, Yn;
                 if (first) { Yk = {mk[j], 0.f}; Yn = {mn[j], 0.f}; }
                 else {
@@ -200,7 +203,7 @@ void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, f
     while (run > 1 && ((size_t)(run - 1) * p.hop + p.win) * 4 > 24 * 1024) --run;
     const int runs_per_utt = (T + run - 1) / run;
     const size_t lds = (size_t)((((run - 1) * p.hop + p.win + 3) & ~3) + ((p.win + 3) & ~3)) * 4 +
-                       (size_t)(FFT_TW + GL_WAVES * FFT_LDS) * sizeof(cplx);
+                       (size_t)(FFT_TW + FFT_N / 2 + GL_WAVES * FFT_LDS) * sizeof(cplx);
     static bool attr_set = false;
     if (!attr_set) {   // more than the default 64 KB of dynamic LDS
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter_kernel),
