@@ -13,12 +13,13 @@
 
 namespace taco {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) {
-    // 1 - 2/(e^{2x}+1): absolute error ~1e-7, saturates cleanly at +-1
-    const float e = expf(2.f * x);
-    return 1.f - 2.f / (e + 1.f);
+// gate non-linearities on the hardware exp2 / rcp (absolute error ~2e-7, saturate cleanly): they sit on the
+// recurrence's dependency chain, the library expf + IEEE divide are several times the instructions
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
+__device__ __forceinline__ float tanhf_(float x) { return fast_tanh(x); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(BIGRU_THREADS) void bigru_scan_kernel(
     const float* __restrict__ xp, const float* __restrict__ Pg, const float* __restrict__ Pc,
@@ -79,16 +80,14 @@ __global__ __launch_bounds__(BIGRU_THREADS) void bigru_scan_kernel(
         // ---- gates
         {
             const float4* h4 = reinterpret_cast<const float4*>(h + 64 * half);
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};     // packed fp32 FMAs: two MACs per instruction
 #pragma unroll
             for (int i = 0; i < KG / 4; ++i) {
                 const float4 hv = h4[i];
-                a0 = fmaf(wg[4 * i + 0], hv.x, a0);
-                a1 = fmaf(wg[4 * i + 1], hv.y, a1);
-                a2 = fmaf(wg[4 * i + 2], hv.z, a2);
-                a3 = fmaf(wg[4 * i + 3], hv.w, a3);
+                a01 = __builtin_elementwise_fma(f32x2{wg[4 * i + 0], wg[4 * i + 1]}, f32x2{hv.x, hv.y}, a01);
+                a23 = __builtin_elementwise_fma(f32x2{wg[4 * i + 2], wg[4 * i + 3]}, f32x2{hv.z, hv.w}, a23);
             }
-            float acc = (a0 + a1) + (a2 + a3);
+            float acc = (a01.x + a01.y) + (a23.x + a23.y);
             acc += dpp_mov<0xB1>(acc);             // lane ^ 1 (DPP quad_perm, no LDS round trip)
             if (half == 0) {
                 const float g = sigmoidf_(acc + xg);
@@ -100,16 +99,14 @@ __global__ __launch_bounds__(BIGRU_THREADS) void bigru_scan_kernel(
         // ---- candidate + state update
         {
             const float4* r4 = reinterpret_cast<const float4*>(rh + 32 * q);
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < KC / 4; ++i) {
                 const float4 rv = r4[i];
-                a0 = fmaf(wc[4 * i + 0], rv.x, a0);
-                a1 = fmaf(wc[4 * i + 1], rv.y, a1);
-                a2 = fmaf(wc[4 * i + 2], rv.z, a2);
-                a3 = fmaf(wc[4 * i + 3], rv.w, a3);
+                a01 = __builtin_elementwise_fma(f32x2{wc[4 * i + 0], wc[4 * i + 1]}, f32x2{rv.x, rv.y}, a01);
+                a23 = __builtin_elementwise_fma(f32x2{wc[4 * i + 2], wc[4 * i + 3]}, f32x2{rv.z, rv.w}, a23);
             }
-            float acc = (a0 + a1) + (a2 + a3);
+            float acc = (a01.x + a01.y) + (a23.x + a23.y);
             acc += dpp_mov<0xB1>(acc);             // lane ^ 1
             acc += dpp_mov<0x4E>(acc);             // lane ^ 2
             if (q == 0) {
