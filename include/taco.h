@@ -114,6 +114,17 @@ int taco_decode(taco_handle h, const float* enc_out, int32_t B, int32_t T_in, in
                 const float* dropout_keep, float* mel, float* align, int32_t* steps_run,
                 void* ws, size_t ws_bytes, taco_stream_t stream);
 
+/* The same loop teacher-forced, as the reference runs it with TrainingHelper (model/helpers.py:6-43,
+ * model/decoder.py:38 when is_training): step 0 is fed the <GO> frame, step t > 0 the target frame
+ * targets[:, t*r - 1, :] ("every r-th target frame", helpers.py:15,42) instead of the previous output; all n_steps
+ * steps run, there is no stop test (helpers.py:41), steps_run receives n_steps.
+ *   targets [B, n_steps*r, num_mels] device fp32; mel, align, dropout_keep as in taco_decode (the reference's
+ *   training graph also has the prenet dropout active: replay its mask through dropout_keep, or pass NULL).
+ * Runs the per-stage kernels (the persistent kernel feeds its own outputs back). */
+int taco_decode_teacher(taco_handle h, const float* enc_out, int32_t B, int32_t T_in, int32_t n_steps,
+                        const float* targets, const float* dropout_keep, float* mel, float* align,
+                        int32_t* steps_run, void* ws, size_t ws_bytes, taco_stream_t stream);
+
 /* Post-processing net: post-CBHG K=8 without sequence lengths + dense to num_freq
  * (model/decoder.py:44-57).  mel [B,T,num_mels] -> linear [B,T,num_freq]. */
 int taco_postnet(taco_handle h, const float* mel, int32_t B, int32_t T, float* linear,

@@ -178,10 +178,12 @@ def encode(ids, lengths, w, hp, stages=None):
                 hp.encoder_highway_depth, hp.encoder_gru_num_cells, stages)
 
 
-def decode(enc_out, w, hp, max_iters=None, return_scores=False):
+def decode(enc_out, w, hp, max_iters=None, return_scores=False, targets=None):
     """decoder.py:18-42 + rnn_wrappers.py:24-26,51-53 + helpers.py:66-78 + TF's AttentionWrapper /
     BahdanauAttention / dynamic_decode (A.7). Returns (mel [B,steps*r,M], alignments
-    [B,T_in,steps], steps_run[, scores [steps,B,T_in]])."""
+    [B,T_in,steps], steps_run[, scores [steps,B,T_in]]).
+    targets [B,T_out,M]: teacher-forced as TrainingHelper does (helpers.py:6-43): the fed frames are
+    targets[:, r-1::r], one step per fed frame, no stop test."""
     dt = enc_out.dtype
     B, T_in, _ = enc_out.shape
     A = hp.attention_depth
@@ -189,6 +191,10 @@ def decode(enc_out, w, hp, max_iters=None, return_scores=False):
     M = hp.num_mels
     r = hp.outputs_per_step
     S = hp.max_iters if max_iters is None else max_iters
+    fed = None
+    if targets is not None:
+        fed = np.asarray(targets, dt)[:, r - 1::r, :]                 # helpers.py:15
+        S = min(S, fed.shape[1]) if max_iters is not None else fed.shape[1]   # helpers.py:18-19,41
     keys = enc_out @ w['memory_layer/kernel']                    # BahdanauAttention memory_layer, no bias
     values = enc_out
     Wq = w[_ATTW + 'bahdanau_attention/query_layer/kernel']
@@ -219,8 +225,11 @@ def decode(enc_out, w, hp, max_iters=None, return_scores=False):
         outs.append(out)
         aligns.append(a)
         scores.append(e)
-        prev = out[:, -M:]                                        # helpers.py:77
-        finished = finished | np.all(out == 0.0, axis=1)          # helpers.py:75 + dynamic_decode's OR
+        if fed is None:
+            prev = out[:, -M:]                                    # helpers.py:77
+            finished = finished | np.all(out == 0.0, axis=1)      # helpers.py:75 + dynamic_decode's OR
+        else:
+            prev = fed[:, steps, :]                               # helpers.py:42 (time = steps)
         steps += 1
     mel = np.stack(outs, 1).reshape(B, steps * r, M)              # decoder.py:42
     align = np.stack(aligns, 0).transpose(1, 2, 0)                # tacotron.py:51

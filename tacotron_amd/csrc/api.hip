@@ -411,6 +411,7 @@ size_t dec_ws_bytes(const taco_ctx* c, int B, int T_in, int S) {
     n += al((size_t)S * NR * Bp * 4);                                        // outQ
     n += al((size_t)S * B * T_in * 4);                                       // alignS
     n += al((size_t)S * Bp * 4);                                             // nz
+    n += al((size_t)S * hp.num_mels * Bp * 4);                               // teacher frames (taco_decode_teacher)
     n += al(((size_t)PD_REGION_DIMS * Bp * 2 + 4096 + (size_t)B * T_in * 2 + 64 + (size_t)S * 400 * Bp * 2) * 4) + 4096;  // persistent decoder region
     const size_t state = (size_t)(hp.num_mels + Dv + hp.attention_depth + 2 * hp.decoder_depth) * Bp * 4;
     n += al(state);
@@ -708,7 +709,7 @@ struct DecBufs {
 };
 
 static void decode_steps(taco_ctx* c, const DecBufs& d, const float* enc_out, const float* keep, int B, int T_in,
-                         int S, hipStream_t s, Timing* tm) {
+                         int S, hipStream_t s, Timing* tm, const float* teachQ = nullptr) {
     const TacoHParams& hp = c->hp;
     const int Bp = bpad16(B);
     const int NR = hp.num_mels * hp.outputs_per_step;
@@ -716,7 +717,11 @@ static void decode_steps(taco_ctx* c, const DecBufs& d, const float* enc_out, co
     const int A = hp.attention_depth, D = hp.decoder_depth;
     const int keep_ld = hp.prenet_depth1 + hp.prenet_depth2;
     for (int st = 0; st < S; ++st) {
-        const float* prev = st == 0 ? d.go : d.outQ + ((size_t)(st - 1) * NR + (NR - hp.num_mels)) * Bp;
+        // previous frame: <GO>, then the last of the r frames just produced (helpers.py:77) or, teacher-forced, the
+        // matching target frame (helpers.py:42)
+        const float* prev = st == 0 ? d.go
+                          : teachQ ? teachQ + (size_t)(st - 1) * hp.num_mels * Bp
+                                   : d.outQ + ((size_t)(st - 1) * NR + (NR - hp.num_mels)) * Bp;
         const float* kp = keep ? keep + (size_t)st * B * keep_ld : nullptr;
         DecGemmArgs a{};
         a.B = B; a.Bpad = Bp;
@@ -809,7 +814,7 @@ void persist_launched(int device, int wgs, hipStream_t s) {
 }  // namespace
 
 static int decode_impl(taco_ctx* c, const float* enc_out, int B, int T_in, int S, const float* keep, float* mel,
-                       float* align, int32_t* steps_run, Carver& ws, hipStream_t s) {
+                       float* align, int32_t* steps_run, Carver& ws, hipStream_t s, const float* teacher = nullptr) {
     const TacoHParams& hp = c->hp;
     Timing* tm = c->timing_on ? &c->timing : nullptr;
     const int Bp = bpad16(B);
@@ -865,7 +870,7 @@ static int decode_impl(taco_ctx* c, const float* enc_out, int B, int T_in, int S
     const size_t pe_floats = (((size_t)B * T_in * 2) + 63) & ~(size_t)63;
     // granule buffers of dec_persistent.hip: [h_att;ctx] x2, h1 x2, h2 x2, p1, p2, rh x3, u x3, q, d0, o1, o2
     const size_t pregion_floats = (size_t)PD_REGION_DIMS * g1 + pe_floats + (size_t)S * 400 * g1;
-    if (c->decode_mode == 2 && default_sizes && !keep && !fine_timing && Bp / 16 <= 8 &&
+    if (c->decode_mode == 2 && default_sizes && !keep && !teacher && !fine_timing && Bp / 16 <= 8 &&
         pregion_floats * 4 < (size_t)1 << 31) {
         float* pregion = ws.take<float>(pregion_floats + 1024);   // + 4 KB tail for diagnostic stamps (PD_STAMPS builds)
         if (!ws.ok()) return fail("taco_decode: workspace too small");
@@ -903,12 +908,19 @@ static int decode_impl(taco_ctx* c, const float* enc_out, int B, int T_in, int S
     }
 
     // ---- modes 0/1: one kernel per stage; eager, or captured once per shape/buffer set and replayed
+    float* teachQ = nullptr;
+    if (teacher) {
+        teachQ = ws.take<float>((size_t)S * hp.num_mels * Bp);
+        if (!ws.ok()) return fail("taco_decode: workspace too small");
+    }
     auto enqueue = [&](Timing* t) {
         keys_gemm(t);
-        decode_steps(c, d, enc_out, keep, B, T_in, S, s, t);
-        launch_dec_finalize(d.outQ, 0, d.alignS, d.nz, S, NR, B, Bp, T_in, mel, align, steps_run, s, t);
+        if (teacher) launch_dec_pack_teacher(teacher, teachQ, S, hp.outputs_per_step, hp.num_mels, B, Bp, s);
+        decode_steps(c, d, enc_out, keep, B, T_in, S, s, t, teachQ);
+        // teacher-forced: TrainingHelper runs all its steps, there is no stop test (helpers.py:41)
+        launch_dec_finalize(d.outQ, 0, d.alignS, d.nz, S, NR, B, Bp, T_in, mel, align, steps_run, s, t, !teacher);
     };
-    if (c->decode_mode == 0 || s == nullptr || (c->timing_on && c->timing.kind != KK_DEC_GRAPH)) {
+    if (c->decode_mode == 0 || teacher || s == nullptr || (c->timing_on && c->timing.kind != KK_DEC_GRAPH)) {
         enqueue(tm);
         return 0;
     }
@@ -949,6 +961,19 @@ extern "C" int taco_decode(taco_handle h, const float* enc_out, int32_t B, int32
     if (decode_impl(h, enc_out, B, T_in, max_iters, dropout_keep, mel, align, steps_run, cv, (hipStream_t)stream))
         return -1;
     return check_launch("taco_decode");
+}
+
+extern "C" int taco_decode_teacher(taco_handle h, const float* enc_out, int32_t B, int32_t T_in, int32_t n_steps,
+                                   const float* targets, const float* dropout_keep, float* mel, float* align,
+                                   int32_t* steps_run, void* ws, size_t ws_bytes, taco_stream_t stream) {
+    if (!h || !enc_out || !targets || !mel || !align || !steps_run || !ws)
+        return fail("taco_decode_teacher: null argument");
+    if (check_dims(B, T_in) || check_dims(B, n_steps)) return -1;
+    HIP_OK(hipSetDevice(h->device));
+    Carver cv(ws, ws_bytes);
+    if (decode_impl(h, enc_out, B, T_in, n_steps, dropout_keep, mel, align, steps_run, cv, (hipStream_t)stream, targets))
+        return -1;
+    return check_launch("taco_decode_teacher");
 }
 
 // ---------------------------------------------------------------------------------------

@@ -308,10 +308,32 @@ __global__ void dec_align_kernel(const float* __restrict__ alignS, const int32_t
     }
 }
 
+// targets [B, S*r, M] -> teachQ[st][M/4][Bpad] quads of frame (st+1)*r - 1, st < S (model/helpers.py:15,42:
+// TrainingHelper feeds every r-th target frame); padded columns zero
+__global__ void dec_pack_teacher_kernel(const float* __restrict__ targets, float4* __restrict__ teachQ, int S, int r,
+                                        int M, int B, int Bpad) {
+    const long total = (long)S * (M / 4) * Bpad;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i % Bpad);
+        const int q = (int)((i / Bpad) % (M / 4));
+        const int st = (int)(i / ((long)Bpad * (M / 4)));
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < B) v = *reinterpret_cast<const float4*>(targets + ((size_t)b * S * r + (size_t)(st + 1) * r - 1) * M + 4 * q);
+        teachQ[i] = v;
+    }
+}
+void launch_dec_pack_teacher(const float* targets, float* teachQ, int S, int r, int M, int B, int Bpad, hipStream_t s) {
+    const long total = (long)S * (M / 4) * Bpad;
+    const int blocks = (int)std::min<long>(1024, (total + 255) / 256);
+    hipLaunchKernelGGL(dec_pack_teacher_kernel, dim3(blocks), dim3(256), 0, s, targets, (float4*)teachQ, S, r, M, B, Bpad);
+}
+
 void launch_dec_finalize(const float* outQ, int gran, const float* alignS, int32_t* nz, int S, int NR, int B, int Bpad,
-                         int T_in, float* mel, float* align, int32_t* steps_run, hipStream_t s, Timing* tm) {
+                         int T_in, float* mel, float* align, int32_t* steps_run, hipStream_t s, Timing* tm,
+                         bool stop_test) {
     if (tm) tm->begin(KK_DEC_MISC, s);
-    hipLaunchKernelGGL(dec_nonzero_kernel, dim3(S), dim3(64), 0, s, outQ, NR / 4, Bpad, gran, nz);
+    if (stop_test) hipLaunchKernelGGL(dec_nonzero_kernel, dim3(S), dim3(64), 0, s, outQ, NR / 4, Bpad, gran, nz);
+    else (void)hipMemsetAsync(nz, 0x01, (size_t)S * Bpad * sizeof(int32_t), s);   // every step "non-zero": no stop
     hipLaunchKernelGGL(dec_steps_kernel, dim3(1), dim3(1024), (size_t)B * 4, s, nz, S, B, Bpad, steps_run);
     long total = (long)B * S * NR;
     int blocks = (int)std::min<long>(2048, (total + 255) / 256);

@@ -111,7 +111,10 @@ void launch_dec_attention(const DecAttnArgs& a, hipStream_t s, Timing* tm);
 
 // outQ [S][NR/4][Bpad][4] -> mel [B][S*NR] (zero past steps*NR); alignS [S][B][T_in] -> align [B][T_in][S].
 void launch_dec_finalize(const float* outQ, int gran, const float* alignS, int32_t* nz, int S, int NR, int B, int Bpad,
-                         int T_in, float* mel, float* align, int32_t* steps_run, hipStream_t s, Timing* tm);
+                         int T_in, float* mel, float* align, int32_t* steps_run, hipStream_t s, Timing* tm,
+                         bool stop_test = true);
+// targets [B, S*r, M] -> teachQ [S][M/4][Bpad][4]: frame (st+1)*r - 1 of every utterance, the input of step st+1
+void launch_dec_pack_teacher(const float* targets, float* teachQ, int S, int r, int M, int B, int Bpad, hipStream_t s);
 
 // Persistent decoder (dec_persistent.hip), default layer sizes only. Offsets o_* are in floats from `region`,
 // the contiguous, zero-filled block of granule buffers the workgroups exchange through (sc1 stores / loads):

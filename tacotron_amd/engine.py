@@ -127,11 +127,27 @@ class TacoEngine:
         self._leave()
         return enc
 
-    def decode(self, enc_out, max_iters=None, dropout_keep=None):
+    def decode(self, enc_out, max_iters=None, dropout_keep=None, targets=None):
+        """Free-running decode (TestingHelper), or teacher-forced when `targets` [B, T_out, num_mels] is given
+        (TrainingHelper, model/helpers.py:6-43: T_out // r steps, step t > 0 is fed targets[:, t*r - 1])."""
         enc_out = self._dev(enc_out, torch.float32)
         B, T_in, _ = enc_out.shape
-        S = int(max_iters or self.hp.max_iters)
         r, M = self.hp.outputs_per_step, self.hp.num_mels
+        if targets is not None:
+            targets = self._dev(targets, torch.float32)
+            if targets.dim() != 3 or targets.shape[0] != B or targets.shape[2] != M or targets.shape[1] < r:
+                raise TacoError('targets must be [B, T_out >= r, num_mels]')
+            # len(targets[:, r-1::r]) steps (helpers.py:15,18), bounded by maximum_iterations (decoder.py:40)
+            S = (targets.shape[1] - (r - 1) + r - 1) // r
+            if max_iters:
+                S = min(S, int(max_iters))
+            if targets.shape[1] < S * r:      # the last group is incomplete: only its first frames exist
+                pad = torch.zeros(B, S * r - targets.shape[1], M, dtype=torch.float32, device=self.device)
+                targets = torch.cat([targets, pad], 1)
+            targets = targets[:, :S * r].contiguous()
+            targets.record_stream(self.stream)
+        else:
+            S = int(max_iters or self.hp.max_iters)
         ws = self._workspace(B, T_in, S)
         mel = self._empty((B, S * r, M,), torch.float32)
         align = self._empty((B, T_in, S,), torch.float32)
@@ -143,10 +159,16 @@ class TacoEngine:
             if tuple(keep.shape) != (S, B, sum(self.hp.prenet_depths)):
                 raise TacoError('dropout_keep must be [max_iters, B, %d]' % sum(self.hp.prenet_depths))
         self._enter()
-        self._check(self.lib.taco_decode(self.handle, enc_out.data_ptr(), B, T_in, S,
-                                         keep.data_ptr() if keep is not None else None,
-                                         mel.data_ptr(), align.data_ptr(), steps.data_ptr(),
-                                         ws.data_ptr(), ws.numel(), self._s))
+        if targets is not None:
+            self._check(self.lib.taco_decode_teacher(self.handle, enc_out.data_ptr(), B, T_in, S, targets.data_ptr(),
+                                                     keep.data_ptr() if keep is not None else None,
+                                                     mel.data_ptr(), align.data_ptr(), steps.data_ptr(),
+                                                     ws.data_ptr(), ws.numel(), self._s))
+        else:
+            self._check(self.lib.taco_decode(self.handle, enc_out.data_ptr(), B, T_in, S,
+                                             keep.data_ptr() if keep is not None else None,
+                                             mel.data_ptr(), align.data_ptr(), steps.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), self._s))
         self._leave()
         return mel, align, steps
 

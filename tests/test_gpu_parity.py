@@ -309,3 +309,22 @@ def test_persistent_decode_under_uneven_load(engine, hp, weights):
         torch.cuda.synchronize()
         for e in others:
             e.close()
+
+
+@pytest.mark.parametrize('B,T_in,T_out', [(3, 11, 20), (17, 40, 33)])
+def test_decode_teacher_forced(engine, hp, weights, B, T_in, T_out):
+    """Teacher-forced decode (TrainingHelper, model/helpers.py:6-43) against the oracle; T_out = 33 is not a multiple
+    of r = 5: targets[:, r-1::r] then has 6 frames, the 7th group is dropped as the reference's slice drops it."""
+    rng = np.random.default_rng(5 * B + T_out)
+    enc = rng.standard_normal((B, T_in, 256)) * 0.5
+    targets = rng.standard_normal((B, T_out, hp.num_mels)) * 0.7
+    w64 = O.cast_weights(weights, np.float64)
+    mel_r, al_r, steps_r = O.decode(enc, w64, hp, targets=targets)
+    mel, al, steps = engine.decode(enc.astype(np.float32), targets=targets.astype(np.float32))
+    mel, al = _np(mel), _np(al)
+    assert int(_np(steps)[0]) == steps_r == (T_out - 4 + 4) // 5
+    assert mel.shape == mel_r.shape and al.shape == al_r.shape
+    assert rel_l1(mel, mel_r) < 1e-4 and rel_l1(al, al_r) < 1e-4
+    # and it differs from the free-running decode of the same memory (the targets are really fed)
+    mel_f, _, _ = engine.decode(enc.astype(np.float32), max_iters=steps_r)
+    assert rel_l1(_np(mel_f), mel_r) > 1e-3
