@@ -25,11 +25,16 @@ class Synthesizer:
         print('Constructing model: %s' % model_name)
         restore_dir = '%s-%d' % (checkpoint_dir, restore_step)
         print('Loading checkpoint: %s' % restore_dir)
-        path = restore_dir + '.npz'
-        if not os.path.exists(path):
-            raise FileNotFoundError('%s not found (TF bundle checkpoints %s.index/.data-* are not readable yet)'
-                                    % (path, restore_dir))
-        self.model = Tacotron(hparams=hparams, weights=load_npz(path), device=device)
+        # a checkpoint the reference's tf.train.Saver wrote (model/tacotron.py:169: <dir>/model.ckpt-<step>.index +
+        # .data-*), or this package's flat .npz form
+        if os.path.exists(restore_dir + '.index'):
+            from .tf_checkpoint import load_tacotron_weights
+            weights = load_tacotron_weights(restore_dir, hparams)
+        elif os.path.exists(restore_dir + '.npz'):
+            weights = load_npz(restore_dir + '.npz')
+        else:
+            raise FileNotFoundError('neither %s.index (TF checkpoint) nor %s.npz found' % (restore_dir, restore_dir))
+        self.model = Tacotron(hparams=hparams, weights=weights, device=device)
         return self
 
     def load_random(self, seed=1234, device=0):

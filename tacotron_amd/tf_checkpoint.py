@@ -1,0 +1,332 @@
+"""TF V2 checkpoint ("tensor bundle") reader and writer, no TensorFlow needed.
+
+Replaces `tf.train.Saver().restore(session, checkpoint_path)` of /root/reference/synthesizer.py:32-34 (and the
+save side of model/tacotron.py:133,169) for the variables of the inference graph: reads
+`<prefix>.index` + `<prefix>.data-0000N-of-0000M` as TF 1.15 writes them (format: SURVEY.md Appendix B, restated
+from the published TF / LevelDB sources; TF itself is not installed here and the reference ships no checkpoint,
+so this module is checked against its own writer only - "parity unpinned", tests/test_cpu_tf_checkpoint.py).
+
+  index file  = LevelDB-style immutable table: data blocks of prefix-compressed entries
+                (varint shared, varint non_shared, varint value_len, key suffix, value) + restart array + count,
+                each block followed by a compression byte (0 = none, the bundle writer's setting; 1 = snappy is
+                rejected) and a masked CRC32C; an index block mapping separator keys to block handles; a 48-byte
+                footer (metaindex handle, index handle, padding, magic 0xdb4775248b80fb57).
+  key ""      -> BundleHeaderProto {1: num_shards, 2: endianness, 3: version}
+  key <name>  -> BundleEntryProto {1: dtype, 2: TensorShapeProto{2: dim{1: size}}, 3: shard_id, 4: offset,
+                                   5: size, 6: crc32c (fixed32, masked)}
+  data files  = raw little-endian row-major tensor bytes at [offset, offset + size).
+"""
+import os
+import struct
+
+import numpy as np
+
+TABLE_MAGIC = 0xdb4775248b80fb57
+_DTYPES = {1: np.float32, 2: np.float64, 3: np.int32, 9: np.int64}      # DT_FLOAT, DT_DOUBLE, DT_INT32, DT_INT64
+_DTYPE_IDS = {np.dtype(v): k for k, v in _DTYPES.items()}
+
+
+class CheckpointError(ValueError):
+    pass
+
+
+# ---- CRC32C (Castagnoli), masked as LevelDB / TF store it ---------------------------------------------------
+_CRC_TABLE = None
+
+
+def _crc_table():
+    global _CRC_TABLE
+    if _CRC_TABLE is None:
+        t = []
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+            t.append(c)
+        _CRC_TABLE = t
+    return _CRC_TABLE
+
+
+def crc32c(data, crc=0):
+    t = _crc_table()
+    c = crc ^ 0xFFFFFFFF
+    for b in bytes(data):
+        c = t[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def mask_crc(c):
+    return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xa282ead8) & 0xFFFFFFFF
+
+
+# ---- varints / minimal protobuf -----------------------------------------------------------------------------
+def _get_varint(buf, pos):
+    out, shift = 0, 0
+    while True:
+        if pos >= len(buf):
+            raise CheckpointError('truncated varint')
+        b = buf[pos]
+        pos += 1
+        out |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return out, pos
+        shift += 7
+        if shift > 70:
+            raise CheckpointError('varint too long')
+
+
+def _put_varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _parse_proto(buf):
+    """{field: [values]} with varints as int, fixed32/64 as int, length-delimited as bytes."""
+    out, pos = {}, 0
+    while pos < len(buf):
+        tag, pos = _get_varint(buf, pos)
+        f, wt = tag >> 3, tag & 7
+        if wt == 0:
+            v, pos = _get_varint(buf, pos)
+        elif wt == 1:
+            v = struct.unpack_from('<Q', buf, pos)[0]
+            pos += 8
+        elif wt == 2:
+            n, pos = _get_varint(buf, pos)
+            v = bytes(buf[pos:pos + n])
+            if len(v) != n:
+                raise CheckpointError('truncated protobuf field')
+            pos += n
+        elif wt == 5:
+            v = struct.unpack_from('<I', buf, pos)[0]
+            pos += 4
+        else:
+            raise CheckpointError('unsupported protobuf wire type %d' % wt)
+        out.setdefault(f, []).append(v)
+    return out
+
+
+def _field(f, wt, payload):
+    return _put_varint((f << 3) | wt) + payload
+
+
+# ---- table reading ------------------------------------------------------------------------------------------
+def _read_block(buf, offset, size, verify=True):
+    block = buf[offset:offset + size]
+    trailer = buf[offset + size:offset + size + 5]
+    if len(block) != size or len(trailer) != 5:
+        raise CheckpointError('block handle (%d, %d) outside the index file' % (offset, size))
+    if trailer[0] != 0:
+        raise CheckpointError('compressed table block (type %d): only uncompressed bundles are supported' % trailer[0])
+    if verify:
+        want = struct.unpack('<I', trailer[1:5])[0]
+        got = mask_crc(crc32c(bytes(block) + bytes(trailer[:1])))
+        if want != got:
+            raise CheckpointError('index file block at %d fails its CRC32C' % offset)
+    return block
+
+
+def _block_entries(block):
+    if len(block) < 4:
+        raise CheckpointError('table block too short')
+    n_restarts = struct.unpack_from('<I', block, len(block) - 4)[0]
+    end = len(block) - 4 - 4 * n_restarts
+    if end < 0:
+        raise CheckpointError('bad restart array')
+    pos, key = 0, b''
+    while pos < end:
+        shared, pos = _get_varint(block, pos)
+        non_shared, pos = _get_varint(block, pos)
+        vlen, pos = _get_varint(block, pos)
+        if shared > len(key) or pos + non_shared + vlen > end:
+            raise CheckpointError('corrupt table entry')
+        key = key[:shared] + bytes(block[pos:pos + non_shared])
+        pos += non_shared
+        yield key, bytes(block[pos:pos + vlen])
+        pos += vlen
+
+
+def read_index(prefix, verify=True):
+    """{name: dict(dtype, shape, shard_id, offset, size, crc32c)}, header dict."""
+    path = prefix + '.index'
+    with open(path, 'rb') as f:
+        buf = f.read()
+    if len(buf) < 48:
+        raise CheckpointError('%s: shorter than a table footer' % path)
+    footer = buf[-48:]
+    if struct.unpack('<Q', footer[40:])[0] != TABLE_MAGIC:
+        raise CheckpointError('%s: not a TF tensor-bundle index (bad magic)' % path)
+    pos = 0
+    _, pos = _get_varint(footer, pos)       # metaindex handle (unused)
+    _, pos = _get_varint(footer, pos)
+    ioff, pos = _get_varint(footer, pos)
+    isize, pos = _get_varint(footer, pos)
+    entries, header = {}, None
+    for _, handle in _block_entries(_read_block(buf, ioff, isize, verify)):
+        boff, p = _get_varint(handle, 0)
+        bsize, p = _get_varint(handle, p)
+        for key, value in _block_entries(_read_block(buf, boff, bsize, verify)):
+            msg = _parse_proto(value)
+            if key == b'':
+                header = dict(num_shards=msg.get(1, [1])[0], endianness=msg.get(2, [0])[0])
+                continue
+            shape = []
+            if 2 in msg:
+                for dim in _parse_proto(msg[2][0]).get(2, []):
+                    shape.append(_parse_proto(dim).get(1, [0])[0])
+            if 7 in msg:
+                raise CheckpointError('%s: sliced (partitioned) variables are not supported' % key.decode())
+            entries[key.decode('utf-8')] = dict(dtype=msg.get(1, [0])[0], shape=tuple(shape),
+                                                shard_id=msg.get(3, [0])[0], offset=msg.get(4, [0])[0],
+                                                size=msg.get(5, [0])[0], crc32c=msg.get(6, [None])[0])
+    if header is None:
+        raise CheckpointError('%s: no bundle header entry' % path)
+    if header['endianness'] != 0:
+        raise CheckpointError('%s: big-endian bundle' % path)
+    return entries, header
+
+
+def read_checkpoint(prefix, names=None, verify_crc=False):
+    """{name: ndarray} of the bundle's tensors (all, or only `names`). verify_crc also checks every tensor's
+    CRC32C (pure Python: slow for large tensors; the index blocks are always checked)."""
+    entries, header = read_index(prefix)
+    out, files = {}, {}
+    try:
+        for name, e in entries.items():
+            if names is not None and name not in names:
+                continue
+            if e['dtype'] not in _DTYPES:
+                raise CheckpointError('%s: unsupported dtype enum %d' % (name, e['dtype']))
+            dt = np.dtype(_DTYPES[e['dtype']])
+            count = int(np.prod(e['shape'], dtype=np.int64)) if e['shape'] else 1
+            if count * dt.itemsize != e['size']:
+                raise CheckpointError('%s: %d bytes stored for shape %s of %s' % (name, e['size'], e['shape'], dt))
+            sid = e['shard_id']
+            if sid not in files:
+                files[sid] = open('%s.data-%05d-of-%05d' % (prefix, sid, header['num_shards']), 'rb')
+            f = files[sid]
+            f.seek(e['offset'])
+            raw = f.read(e['size'])
+            if len(raw) != e['size']:
+                raise CheckpointError('%s: data shard %d is truncated' % (name, sid))
+            if verify_crc and e['crc32c'] is not None and mask_crc(crc32c(raw)) != e['crc32c']:
+                raise CheckpointError('%s: tensor bytes fail their CRC32C' % name)
+            out[name] = np.frombuffer(raw, dtype=dt.newbyteorder('<')).astype(dt).reshape(e['shape'])
+    finally:
+        for f in files.values():
+            f.close()
+    return out
+
+
+# ---- writing (the save side; also what the reader is tested against) -----------------------------------------
+def _build_block(items, restart_interval=16):
+    out, restarts, prev = bytearray(), [], b''
+    for i, (key, value) in enumerate(items):
+        shared = 0
+        if i % restart_interval == 0:
+            restarts.append(len(out))
+        else:
+            while shared < min(len(prev), len(key)) and prev[shared] == key[shared]:
+                shared += 1
+        out += _put_varint(shared) + _put_varint(len(key) - shared) + _put_varint(len(value))
+        out += key[shared:] + value
+        prev = key
+    if not restarts:
+        restarts = [0]
+    for r in restarts:
+        out += struct.pack('<I', r)
+    out += struct.pack('<I', len(restarts))
+    return bytes(out)
+
+
+def write_checkpoint(prefix, tensors, block_bytes=4096):
+    """Write {name: ndarray} as a one-shard bundle (sorted keys, uncompressed blocks, CRCs filled in)."""
+    names = sorted(tensors, key=lambda n: n.encode('utf-8'))
+    data = bytearray()
+    items = [(b'', _field(1, 0, _put_varint(1)) + _field(2, 0, _put_varint(0)) +
+              _field(3, 2, _put_varint(2) + _field(1, 0, _put_varint(1))))]     # version {producer: 1}
+    for n in names:
+        a = np.asarray(tensors[n], order='C')
+        if a.dtype not in _DTYPE_IDS:
+            raise CheckpointError('%s: dtype %s cannot be stored' % (n, a.dtype))
+        raw = a.astype(a.dtype.newbyteorder('<')).tobytes()
+        shape = b''.join(_field(2, 2, (lambda d: _put_varint(len(d)) + d)(_field(1, 0, _put_varint(int(s)))))
+                         for s in a.shape)
+        msg = _field(1, 0, _put_varint(_DTYPE_IDS[a.dtype])) + _field(2, 2, _put_varint(len(shape)) + shape)
+        if len(data):
+            msg += _field(4, 0, _put_varint(len(data)))
+        msg += _field(5, 0, _put_varint(len(raw))) + _field(6, 5, struct.pack('<I', mask_crc(crc32c(raw))))
+        items.append((n.encode('utf-8'), msg))
+        data += raw
+    out = bytearray()
+
+    def emit(block):
+        off = len(out)
+        out.extend(block)
+        out.extend(b'\x00' + struct.pack('<I', mask_crc(crc32c(block + b'\x00'))))
+        return _put_varint(off) + _put_varint(len(block))
+
+    index_items, cur, cur_bytes = [], [], 0
+    for kv in items:
+        cur.append(kv)
+        cur_bytes += len(kv[0]) + len(kv[1]) + 3
+        if cur_bytes >= block_bytes:
+            index_items.append((cur[-1][0], emit(_build_block(cur))))
+            cur, cur_bytes = [], 0
+    if cur:
+        index_items.append((cur[-1][0], emit(_build_block(cur))))
+    meta = emit(_build_block([]))
+    index = emit(_build_block(index_items, restart_interval=1))
+    footer = meta + index
+    footer += b'\x00' * (40 - len(footer)) + struct.pack('<Q', TABLE_MAGIC)
+    out.extend(footer)
+    os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
+    with open(prefix + '.index', 'wb') as f:
+        f.write(bytes(out))
+    with open('%s.data-00000-of-00001' % prefix, 'wb') as f:
+        f.write(bytes(data))
+
+
+# ---- the reference's variables ---------------------------------------------------------------------------------
+GRAPH_PREFIX = 'model/inference/'      # scopes of synthesizer.py:23 and model/tacotron.py:31
+
+
+def load_tacotron_weights(prefix, hp=None, verify_crc=False):
+    """The inference-graph variables of a checkpoint the reference saved (model/tacotron.py:169), as the
+    {name relative to model/inference/: float32 array} dict the engine takes. Optimiser slots (`.../Adam`,
+    `.../Adam_1`, `model/optimizer/...`) and `global_step` are skipped; anything else that does not fit the graph is
+    reported by name and shape."""
+    from .weights import check_weights, variable_specs
+    want = {n for n, _, _ in variable_specs(hp)}
+    entries, _ = read_index(prefix)
+    pick, ignored, strange = {}, [], []
+    for name in entries:
+        if not name.startswith(GRAPH_PREFIX):
+            ignored.append(name)
+            continue
+        rel = name[len(GRAPH_PREFIX):]
+        if rel in want:
+            pick[name] = rel
+        elif rel.endswith('/Adam') or rel.endswith('/Adam_1') or rel == 'global_step':
+            ignored.append(name)
+        else:
+            strange.append('%s %s' % (name, entries[name]['shape']))
+    if strange:
+        raise CheckpointError('variables under %s that the inference graph does not have:\n  %s'
+                              % (GRAPH_PREFIX, '\n  '.join(strange)))
+    raw = read_checkpoint(prefix, names=set(pick), verify_crc=verify_crc)
+    w = {pick[k]: np.asarray(v, np.float32) for k, v in raw.items()}
+    check_weights(w, hp)      # lists every missing / mis-shaped variable
+    return w
+
+
+def save_tacotron_weights(prefix, w):
+    """Weights dict -> bundle under the reference's variable names (readable by tf.train.Saver)."""
+    write_checkpoint(prefix, {GRAPH_PREFIX + k: np.asarray(v, np.float32) for k, v in w.items()})

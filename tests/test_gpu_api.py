@@ -81,6 +81,26 @@ def test_checkpoint_roundtrip_through_synthesizer(tmp_path, hp, weights):
         hparams.max_iters = old
 
 
+def test_tf_checkpoint_through_synthesizer(tmp_path, hp, weights):
+    """Synthesizer.load on a TF V2 bundle under the reference's variable names (synthesizer.py:32-34); the bundle
+    comes from this package's own writer (no TF here: real-checkpoint compatibility is unpinned)."""
+    from tacotron_amd import synthesizer as S
+    from tacotron_amd.hparams import hparams
+    from tacotron_amd.tf_checkpoint import save_tacotron_weights
+    save_tacotron_weights(str(tmp_path / 'model.ckpt-77'), weights)
+    old = hparams.max_iters
+    hparams.max_iters = 3
+    try:
+        s = S.Synthesizer().load(str(tmp_path / 'model.ckpt'), 77)
+        ids, lens = synth_ids(np.random.default_rng(3), 2, 9)
+        s.model.initialize(ids, lens)
+        ref = O.tacotron_forward(ids, lens, weights, hp, max_iters=3)
+        assert rel_l1(_np(s.model.linear_outputs), ref['linear']) < 1e-3
+        s.model.engine.close()
+    finally:
+        hparams.max_iters = old
+
+
 def test_full_length_parity_cfg1(engine, hp, weights):
     """BASELINE configs[0] shape (T_in=150, 200 decoder steps -> 1000 frames) against the fp64 oracle after all 200
     feedback steps: mel/linear within 1e-3 relative L1; attention argmax identical wherever the oracle's margin
