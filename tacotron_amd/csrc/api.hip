@@ -230,13 +230,17 @@ struct Loader {
             if (!Hk || !Hb || !Tk || !Tb) return false;
             ConvW& w = cb.hw[i - 1];
             w.Cin = D; w.taps = 1; w.padl = 0; w.N = 2 * D; w.ldw = (2 * D + 127) / 128 * 128;
+            // columns in blocks of 64 = [32 H | 32 T] of the same 32 units (ACT_HIGHWAY_FUSED, kernels.h)
             std::vector<float> h((size_t)D * w.ldw, 0.f), bias(2 * D);
-            for (int k = 0; k < D; ++k) {
-                memcpy(&h[(size_t)k * w.ldw], Hk->data + (size_t)k * D, D * sizeof(float));
-                memcpy(&h[(size_t)k * w.ldw + D], Tk->data + (size_t)k * D, D * sizeof(float));
+            for (int u = 0; u < D; ++u) {
+                const int ch = (u / 32) * 64 + (u % 32), ct = ch + 32;
+                for (int k = 0; k < D; ++k) {
+                    h[(size_t)k * w.ldw + ch] = Hk->data[(size_t)k * D + u];
+                    h[(size_t)k * w.ldw + ct] = Tk->data[(size_t)k * D + u];
+                }
+                bias[ch] = Hb->data[u];
+                bias[ct] = Tb->data[u];
             }
-            memcpy(&bias[0], Hb->data, D * sizeof(float));
-            memcpy(&bias[D], Tb->data, D * sizeof(float));
             w.W = upload(h);
             w.bias = upload(bias);
             if (!w.W || !w.bias) return false;
@@ -391,7 +395,6 @@ size_t cbhg_ws_bytes(const CbhgW& cb, size_t M) {
     n += al(M * cb.proj1 * 4);                 // proj1
     n += al(M * cb.proj2 * 4);                 // proj2 + residual
     n += 2 * al(M * cb.highway_depth * 4);     // highway ping-pong
-    n += al(M * 2 * cb.highway_depth * 4);     // [H|T]
     n += al(M * 6 * cb.gru * 4);               // rnn input projections
     const int sk = conv_gemm_pick_splitk((int)M, cb.proj1, cb.p1.taps * cb.p1.Cin / 16);
     if (sk > 1) n += al((size_t)sk * M * ((cb.proj1 + 63) / 64 * 64) * 4);   // proj_1 split-K partial sums
@@ -437,7 +440,6 @@ int run_cbhg(taco_ctx* c, const CbhgW& cb, const float* x, const int32_t* lens, 
     float* p2 = ws.take<float>((size_t)M * cb.proj2);
     float* hwA = ws.take<float>((size_t)M * cb.highway_depth);
     float* hwB = ws.take<float>((size_t)M * cb.highway_depth);
-    float* HT = ws.take<float>((size_t)M * 2 * cb.highway_depth);
     float* xp = ws.take<float>((size_t)M * 6 * cb.gru);
     const int sk = conv_gemm_pick_splitk(M, cb.proj1, cb.p1.taps * cb.p1.Cin / 16);
     float* p1part = sk > 1 ? ws.take<float>((size_t)sk * M * ((cb.proj1 + 63) / 64 * 64)) : nullptr;
@@ -471,11 +473,11 @@ int run_cbhg(taco_ctx* c, const CbhgW& cb, const float* x, const int32_t* lens, 
     // highway layers (modules.py:87-88,100-123)
     for (int i = 0; i < cb.n_highway; ++i) {
         const ConvW& w = cb.hw[i];
-        g = GemmArgs{h, cb.highway_depth, M, T, w.Cin, 1, 0, w.W, w.ldw, w.N, w.bias, nullptr, nullptr, nullptr, 0,
-                     HT, 2 * cb.highway_depth, ACT_HIGHWAY_SPLIT, 0};
-        launch_conv_gemm(g, s, tm);
+        // y = H*T + x*(1-T) in the GEMM's epilogue: the [H|T] matrix is never written
         float* nxt = (h == hwA) ? hwB : hwA;
-        launch_highway_combine(HT, h, nxt, M, cb.highway_depth, s, tm);
+        g = GemmArgs{h, cb.highway_depth, M, T, w.Cin, 1, 0, w.W, w.ldw, w.N, w.bias, nullptr, nullptr, h,
+                     cb.highway_depth, nxt, cb.highway_depth, ACT_HIGHWAY_FUSED, 0};
+        launch_conv_gemm(g, s, tm);
         h = nxt;
     }
     // BiGRU (modules.py:92-98): input halves as one GEMM, then the scan
@@ -513,6 +515,8 @@ extern "C" int taco_create(const TacoHParams* hp, const TacoWeightEntry* weights
         !m16(p.decoder_depth) || !m16(p.num_mels) || !m16(p.decoder_bank_filters) || !m16(p.decoder_proj1) ||
         !m16(p.decoder_proj2) || !m16(p.decoder_highway_depth))
         return fail("taco_create: every layer width must be a positive multiple of 16");
+    if (p.encoder_highway_depth % 32 || p.decoder_highway_depth % 32)
+        return fail("taco_create: highway depths must be multiples of 32 (fused highway epilogue)");
     if (p.encoder_gru_cells != BIGRU_H || p.decoder_gru_cells != BIGRU_H)
         return fail("taco_create: the BiGRU scan kernel is built for %d cells per direction", BIGRU_H);
     if (p.encoder_proj2 != p.prenet_depth2 || p.decoder_proj2 != p.num_mels)

@@ -21,12 +21,11 @@ __device__ __forceinline__ float4 max4(float4 a, float4 b) {
     return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
 }
 
-__device__ __forceinline__ float apply_act(float v, int act, bool second_half) {
+__device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case ACT_RELU: return fmaxf(v, 0.f);
         case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
         case ACT_TANH: return tanhf(v);
-        case ACT_HIGHWAY_SPLIT: return second_half ? 1.f / (1.f + expf(-v)) : fmaxf(v, 0.f);
         default: return v;
     }
 }
@@ -204,6 +203,29 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
         }
         return;
     }
+    if constexpr (TN == 2) {
+        if (a.act == ACT_HIGHWAY_FUSED) {
+            // this wave's 64 columns = [32 H | 32 T] of units u0 .. u0+31; the lane holds both for unit u0 + li
+            const int nh = n0 + wn + li, nt = nh + 32;
+            const int unit = (n0 + wn) / 2 + li;
+            if (nt < a.N) {
+                const float bh = bias ? bias[nh] : 0.f, bt = bias ? bias[nt] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                        if (m >= a.M) continue;
+                        const float hh = fmaxf(acc[i][0][r] + bh, 0.f);
+                        const float tt = 1.f / (1.f + expf(-(acc[i][1][r] + bt)));
+                        const float x = a.R[(size_t)m * a.ldr + unit];
+                        C[(size_t)m * a.ldc + unit] = hh * tt + x * (1.f - tt);
+                    }
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn + 32 * j + li;
@@ -211,14 +233,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
         const float bv = bias ? bias[n] : 0.f;
         const float sc = scale ? scale[n] : 1.f;
         const float sh = shift ? shift[n] : 0.f;
-        const bool second = n >= (a.N >> 1);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (m >= a.M) continue;
-                float v = apply_act(acc[i][j][r] + bv, a.act, second);
+                float v = apply_act(acc[i][j][r] + bv, a.act);
                 if (scale) v = v * sc + sh;
                 if (a.R) v += a.R[(size_t)m * a.ldr + n];
                 C[(size_t)m * a.ldc + n] = v;
@@ -244,7 +265,7 @@ __global__ void splitk_epilogue_kernel(GemmArgs a, int ldp) {
         for (int e = 0; e < 4; ++e) {
             const int n = nb + e;
             if (n >= a.N) break;
-            float v = apply_act(vs[e] + (a.bias ? a.bias[n] : 0.f), a.act, n >= (a.N >> 1));
+            float v = apply_act(vs[e] + (a.bias ? a.bias[n] : 0.f), a.act);
             if (a.scale) v = v * a.scale[n] + a.shift[n];
             if (a.R) v += a.R[(size_t)m * a.ldr + n];
             a.C[(size_t)m * a.ldc + n] = v;
@@ -269,7 +290,7 @@ void launch_conv_gemm(const GemmArgs& a_in, hipStream_t s, Timing* tm) {
     const int z = a.splitk > 1 ? a.splitk : groups;
     // tile choice: big tiles when one slice alone still gives ~a block per CU, else 64x64
     const long blocks128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (blocks128 >= 192 && a.N >= 128 && a.splitk == 1) {
+    if ((blocks128 >= 192 && a.N >= 128 && a.splitk == 1) || a.act == ACT_HIGHWAY_FUSED) {
         dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, z);
         hipLaunchKernelGGL((conv_gemm_kernel<128, 128>), grid, dim3(256), 0, s, a);
     } else {
@@ -286,35 +307,6 @@ void launch_conv_gemm(const GemmArgs& a_in, hipStream_t s, Timing* tm) {
 }
 
 // ---------------------------------------------------------------------------------------
-__global__ void highway_combine_kernel(const float4* __restrict__ HT, const float4* __restrict__ x,
-                                       float4* __restrict__ y, long n4, int dq) {
-    // HT row = [H (dq float4) | T (dq float4)], x/y rows = dq float4
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        const long m = i / dq;
-        const int c = (int)(i - m * dq);
-        const float4 H = HT[m * 2 * dq + c];
-        const float4 T = HT[m * 2 * dq + dq + c];
-        const float4 xv = x[i];
-        float4 o;
-        o.x = H.x * T.x + xv.x * (1.f - T.x);
-        o.y = H.y * T.y + xv.y * (1.f - T.y);
-        o.z = H.z * T.z + xv.z * (1.f - T.z);
-        o.w = H.w * T.w + xv.w * (1.f - T.w);
-        y[i] = o;
-    }
-}
-
-void launch_highway_combine(const float* HT, const float* x, float* y, int M, int depth, hipStream_t s, Timing* tm) {
-    if (tm) tm->begin(KK_HIGHWAY, s);
-    const long n4 = (long)M * depth / 4;
-    int blocks = (int)((n4 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(highway_combine_kernel, dim3(blocks), dim3(256), 0, s, (const float4*)HT, (const float4*)x,
-                       (float4*)y, n4, depth / 4);
-    if (tm) tm->end(KK_HIGHWAY, s);
-}
-
 __global__ void embed_gather_kernel(const int32_t* __restrict__ ids, const float4* __restrict__ lut,
                                     float4* __restrict__ out, long n4, int wq, int num_rows) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {

@@ -11,7 +11,7 @@ namespace taco {
 // Kernel families, for taco_timing_begin / taco_kernel_name.
 enum KernelKind : int {
     KK_CONV_GEMM = 0,   // conv_gemm_kernel<*>: dense / conv1d implicit GEMM on fp32 MFMA
-    KK_HIGHWAY,         // highway_combine_kernel
+    KK_HIGHWAY,         // (retired: the highway combine is conv_gemm's ACT_HIGHWAY_FUSED epilogue; never launched)
     KK_GATHER,          // embed_gather_kernel
     KK_BIGRU,           // bigru_scan_kernel (one launch scans all T steps)
     KK_DEC_GEMM,        // dec_gemm_kernel: decoder-step skinny GEMM
@@ -34,7 +34,10 @@ struct Timing {
     void end(int k, hipStream_t s);
 };
 
-enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3, ACT_HIGHWAY_SPLIT = 4 };
+// ACT_HIGHWAY_FUSED: the whole highway layer in the epilogue. W's columns come in blocks of 64 = [32 H | 32 T] of the
+// same 32 units (so that one lane of the 32x32 MFMA layout holds H and T of a unit), R is the layer input x
+// [M, N/2], C the layer output y = relu(H) * sigmoid(T) + x * (1 - sigmoid(T)) [M, N/2] (modules.py:100-123).
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3, ACT_HIGHWAY_FUSED = 5 };
 
 // C[m, n] = epi( sum_{j<taps} sum_{c<Cin} X[b, t+j-padl, c] * W[j*Cin+c, n] ), m = b*T + t.
 // epi(v) = ((act(v + bias[n])) * scale[n] + shift[n]) + R[m, n]   (absent pieces skipped)
@@ -63,9 +66,6 @@ struct GemmArgs {
 };
 int conv_gemm_pick_splitk(int M, int N, int nk);
 void launch_conv_gemm(const GemmArgs& a, hipStream_t s, Timing* tm);
-
-// y = H*T + x*(1-T) with HT = [relu(H) | sigmoid(T)] rows of width 2*depth
-void launch_highway_combine(const float* HT, const float* x, float* y, int M, int depth, hipStream_t s, Timing* tm);
 
 // out[m, :] = lut[clamp(ids[m]), :]  (width floats, multiple of 4)
 void launch_embed_gather(const int32_t* ids, const float* lut, float* out, int M, int width, int num_rows,
