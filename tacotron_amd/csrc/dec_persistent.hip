@@ -686,12 +686,15 @@ size_t dec_persistent_lds_bytes(int T_in, int* lds_keys, int* lds_vals) {
 }
 
 int launch_dec_persistent(DecPersistArgs a, hipStream_t s, Timing* tm) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    // more than the default 64 KB of dynamic LDS: the attribute is per device
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    if (!attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persistent_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return -1;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const size_t lds = dec_persistent_lds_bytes(a.T_in, &a.lds_keys, &a.lds_vals);
     if (tm) tm->begin(KK_DEC_PERSIST, s);

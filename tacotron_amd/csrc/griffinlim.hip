@@ -204,11 +204,12 @@ void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, f
     const int runs_per_utt = (T + run - 1) / run;
     const size_t lds = (size_t)((((run - 1) * p.hop + p.win + 3) & ~3) + ((p.win + 3) & ~3)) * 4 +
                        (size_t)(FFT_TW + FFT_N / 2 + GL_WAVES * FFT_LDS) * sizeof(cplx);
-    static bool attr_set = false;
-    if (!attr_set) {   // more than the default 64 KB of dynamic LDS
+    static bool attr_set[64] = {};   // more than the default 64 KB of dynamic LDS: the attribute is per device
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL(gl_iter_kernel, dim3((unsigned)(B * runs_per_utt)), dim3(GL_THREADS), lds, s, frames_in, mag,
                        frames_out, (const float2*)p.twiddle, p.window, B, T, p.hop, p.win, p.nbins, first, run,
