@@ -390,3 +390,58 @@ def spectrogram_inv_librosa(spect, hp, rng):
         ang = np.exp(1j * np.angle(stft_librosa(y, n_fft, hop, win)))
         y = istft_librosa(Sc * ang, hop, win)
     return pre_emphasis_inv(y, hp.preemphasis)
+
+
+# ----------------------------------------------------------------------------------------
+# analysis side (audio.py:23-42,66-79,91-109,212-264): what data_load._process_utterance stores
+# ----------------------------------------------------------------------------------------
+def pre_emphasis(x, coef=0.97):
+    """scipy.signal.lfilter([1, -coef], [1], x): y[n] = x[n] - coef*x[n-1], zero initial state (audio.py:109)."""
+    x = np.asarray(x, np.float64)
+    y = x.copy()
+    y[1:] -= coef * x[:-1]
+    return y
+
+
+def mel_basis_librosa(sr, n_fft, n_mels):
+    """librosa 0.5.1 filters.mel(sr, n_fft, n_mels, fmin=0, fmax=sr/2, htk=False, norm=1), written filter by filter
+    (an independent formulation of tacotron_amd.tools.audio.build_mel_basis). Library knowledge: unpinned."""
+    f_sp, min_log_hz, logstep = 200.0 / 3, 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+
+    def hz2mel(f):
+        return min_log_mel + np.log(f / min_log_hz) / logstep if f >= min_log_hz else f / f_sp
+
+    def mel2hz(m):
+        return min_log_hz * np.exp(logstep * (m - min_log_mel)) if m >= min_log_mel else f_sp * m
+
+    mmax = hz2mel(sr / 2.0)
+    edges = [mel2hz(mmax * i / (n_mels + 1)) for i in range(n_mels + 2)]
+    freqs = [sr / 2.0 * k / (n_fft // 2) for k in range(1 + n_fft // 2)]
+    W = np.zeros((n_mels, len(freqs)))
+    for i in range(n_mels):
+        lo, ce, hi = edges[i], edges[i + 1], edges[i + 2]
+        for k, f in enumerate(freqs):
+            up = (f - lo) / (ce - lo)
+            down = (hi - f) / (hi - ce)
+            W[i, k] = max(0.0, min(up, down)) * 2.0 / (hi - lo)
+    return W
+
+
+def _normalize(S, hp):
+    return np.clip((S - hp.min_level_db) / -float(hp.min_level_db), 0, 1)
+
+
+def spectrogram_librosa(y, hp):
+    """audio.py:23-42 -> [1025, frames] float64."""
+    n_fft, hop, win = hp.stft_params()
+    D = stft_librosa(pre_emphasis(y, hp.preemphasis), n_fft, hop, win)
+    return _normalize(20 * np.log10(np.maximum(1e-5, np.abs(D))) - hp.ref_level_db, hp)
+
+
+def mel_spectrogram_librosa(y, hp):
+    """audio.py:66-79 -> [num_mels, frames] float64."""
+    n_fft, hop, win = hp.stft_params()
+    D = stft_librosa(pre_emphasis(y, hp.preemphasis), n_fft, hop, win)
+    M = mel_basis_librosa(hp.sample_rate, n_fft, hp.num_mels) @ np.abs(D)
+    return _normalize(20 * np.log10(np.maximum(1e-5, M)) - hp.ref_level_db, hp)

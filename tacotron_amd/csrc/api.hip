@@ -97,6 +97,7 @@ struct taco_ctx {
     float* enc_lut = nullptr;      // prenet(embedding) [num_chars, prenet2]
     CbhgW enc, post;
     ConvW mem_layer, lin_dense;
+    ConvW mel_proj;                // optional "audio/mel_basis" [num_mels, num_freq] as a [ceil16(num_freq), 128] GEMM operand
     DecW pre1, pre2, att_g, att_c, query, proj, g1_g, g1_c, g2_g, g2_c, outp;
     DecW pre1_f, g1_g_f, g1_c_f;   // folded forms for the persistent decoder (Loader::dec_fold)
     DecW att_g_p, g2_g_p;          // row-reordered copies (early inputs first) for the persistent decoder
@@ -617,6 +618,21 @@ extern "C" int taco_create(const TacoHParams* hp, const TacoWeightEntry* weights
     }
     ok = ok && L.cbhg(c->post, "post_cbhg");
     ok = ok && L.conv(c->lin_dense, "dense/kernel", "dense/bias", 0, 2 * p.decoder_gru_cells, p.num_freq);
+    if (ok && L.tab.count("audio/mel_basis")) {
+        // analysis side (taco_spectrogram): the mel filterbank, transposed and zero-padded in K to a multiple of 16
+        const TacoWeightEntry* mb = L.get("audio/mel_basis", {p.num_mels, p.num_freq});
+        ok = mb != nullptr;
+        if (ok) {
+            ConvW& w = c->mel_proj;
+            w.Cin = (p.num_freq + 15) / 16 * 16; w.taps = 1; w.padl = 0; w.N = p.num_mels;
+            w.ldw = (p.num_mels + 127) / 128 * 128;
+            std::vector<float> hw((size_t)w.Cin * w.ldw, 0.f);
+            for (int m = 0; m < p.num_mels; ++m)
+                for (int k = 0; k < p.num_freq; ++k) hw[(size_t)k * w.ldw + m] = mb->data[(size_t)m * p.num_freq + k];
+            w.W = L.upload(hw);
+            ok = w.W != nullptr;
+        }
+    }
     const TacoWeightEntry* emb = ok ? L.get("embedding", {p.num_chars, p.embedded_depth}) : nullptr;
     ok = ok && emb;
     if (ok) {
@@ -1024,6 +1040,43 @@ static int gl_impl(taco_ctx* c, const float* linear, int B, int T, int iters, fl
     }
     launch_gl_ola(p, cur, wav, B, T, s, tm);
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+extern "C" size_t taco_spectrogram_workspace_bytes(taco_handle h, int32_t B, int32_t n_samples) {
+    if (!h || B < 1 || n_samples < 1) return 0;
+    const size_t T = 1 + (size_t)n_samples / h->hp.hop_length;
+    return al((size_t)B * T * ((h->hp.num_freq + 15) / 16 * 16) * 4) + 4096;
+}
+
+extern "C" int taco_spectrogram(taco_handle h, const float* wav, int32_t B, int32_t n_samples, float preemphasis,
+                                float* linear, float* mel, void* ws, size_t ws_bytes, taco_stream_t stream) {
+    if (!h || !wav || !ws || (!linear && !mel)) return fail("taco_spectrogram: null argument");
+    const TacoHParams& hp = h->hp;
+    if (B < 1 || n_samples <= hp.n_fft / 2)
+        return fail("taco_spectrogram: need more than n_fft/2 = %d samples (reflect padding), got %d", hp.n_fft / 2,
+                    n_samples);
+    if (mel && !h->mel_proj.W) return fail("taco_spectrogram: no 'audio/mel_basis' was given to taco_create");
+    const long T = 1 + n_samples / hp.hop_length;
+    if (check_dims(B, (int)T)) return -1;
+    HIP_OK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Timing* tm = h->timing_on ? &h->timing : nullptr;
+    Carver cv(ws, ws_bytes);
+    const int ldm = (hp.num_freq + 15) / 16 * 16;
+    const size_t M = (size_t)B * T;
+    float* mag = cv.take<float>(M * ldm);
+    if (!cv.ok()) return fail("taco_spectrogram: workspace too small");
+    if (ldm != hp.num_freq) HIP_OK(hipMemsetAsync(mag, 0, M * ldm * sizeof(float), s));   // zero K padding
+    GLPlan p{hp.n_fft, hp.hop_length, hp.win_length, hp.num_freq, h->twiddle, h->window};
+    launch_stft_center(p, wav, B, n_samples, (int)T, preemphasis, hp.ref_level_db, hp.min_level_db, mag, ldm, linear, s, tm);
+    if (mel) {
+        const ConvW& w = h->mel_proj;   // _linspect_to_melspect + _amp_to_db - ref + _normalize (audio.py:78-79)
+        GemmArgs g{mag, ldm, (int)M, (int)T, w.Cin, 1, 0, w.W, w.ldw, w.N, nullptr, nullptr, nullptr, nullptr, 0,
+                   mel, w.N, ACT_DB_NORM, 0, nullptr, 0, nullptr, 0, hp.ref_level_db, hp.min_level_db};
+        launch_conv_gemm(g, s, tm);
+    }
+    return check_launch("taco_spectrogram");
 }
 
 extern "C" int taco_griffin_lim(taco_handle h, const float* linear, int32_t B, int32_t T, int32_t iters, float* wav,

@@ -240,6 +240,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
                 const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (m >= a.M) continue;
                 float v = apply_act(acc[i][j][r] + bv, a.act);
+                if (a.act == ACT_DB_NORM)
+                    v = fminf(fmaxf((20.f * log10f(fmaxf(1e-5f, v)) - a.p0 - a.p1) / -a.p1, 0.f), 1.f);
                 if (scale) v = v * sc + sh;
                 if (a.R) v += a.R[(size_t)m * a.ldr + n];
                 C[(size_t)m * a.ldc + n] = v;
@@ -266,6 +268,8 @@ __global__ void splitk_epilogue_kernel(GemmArgs a, int ldp) {
             const int n = nb + e;
             if (n >= a.N) break;
             float v = apply_act(vs[e] + (a.bias ? a.bias[n] : 0.f), a.act);
+            if (a.act == ACT_DB_NORM)
+                v = fminf(fmaxf((20.f * log10f(fmaxf(1e-5f, v)) - a.p0 - a.p1) / -a.p1, 0.f), 1.f);
             if (a.scale) v = v * a.scale[n] + a.shift[n];
             if (a.R) v += a.R[(size_t)m * a.ldr + n];
             a.C[(size_t)m * a.ldc + n] = v;

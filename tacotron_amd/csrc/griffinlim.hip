@@ -217,6 +217,97 @@ void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, f
     if (tm) tm->end(KK_GL_ITER, s);
 }
 
+// ---------------------------------------------------------------------------------------
+// Analysis side (tools/audio.py:23-42,66-79): D = librosa.stft(pre_emphasis(y), n_fft, hop, win, 'hann') with
+// center=True: the pre-emphasised signal is reflect-padded by n_fft/2 on both sides, frame t covers padded samples
+// [t hop, t hop + n_fft) and is weighted by the periodic Hann window of length win zero-padded (centred) to n_fft.
+// One wave per frame, the same register FFT as gl_iter: |D| goes to `mag` (the mel projection's GEMM operand),
+// clip((20 log10(max(1e-5, |D|)) - ref - min) / -min, 0, 1) to `lin`.
+__global__ __launch_bounds__(GL_THREADS, 2) void stft_center_kernel(const float* __restrict__ wav,
+                                                                    const float2* __restrict__ twiddle,
+                                                                    const float* __restrict__ window, int B, int n, int T,
+                                                                    int hop, int win, int nbins, float preemph,
+                                                                    float ref_db, float min_db, float* __restrict__ mag,
+                                                                    int ldm, float* __restrict__ lin) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gl_smem[];
+    cplx* tw_s = reinterpret_cast<cplx*>(gl_smem);
+    const cplx* T2 = tw_s;
+    const cplx* T3 = tw_s + FFT_T2;
+    cplx* wk_s = tw_s + FFT_TW;
+    cplx* fft_s = wk_s + FFT_N / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    cplx* lds = fft_s + wave * FFT_LDS;
+    const cplx* Wt = reinterpret_cast<const cplx*>(twiddle);
+    for (int e = tid; e < FFT_TW; e += GL_THREADS) tw_s[e] = fft_tw_entry(e, Wt);
+    for (int e = tid; e < FFT_N / 2; e += GL_THREADS) wk_s[e] = Wt[e];
+    __syncthreads();
+    const int n_fft = 2 * FFT_N, lp = (n_fft - win) / 2;
+    const long nframes = (long)B * T;
+    for (long f = (long)blockIdx.x * GL_WAVES + wave; f < nframes; f += (long)gridDim.x * GL_WAVES) {
+        const int b = (int)(f / T), t = (int)(f - (long)b * T);
+        const float* x = wav + (size_t)b * n;
+        auto sample = [&](int pidx) -> float {          // padded position -> pre-emphasised, windowed sample
+            const int wi = pidx - lp;
+            if (wi < 0 || wi >= win) return 0.f;
+            int j = t * hop + pidx - n_fft / 2;         // position in the unpadded signal
+            if (j < 0) j = -j;                          // np.pad(mode='reflect')
+            if (j >= n) j = 2 * (n - 1) - j;
+            const float v = x[j] - (j > 0 ? preemph * x[j - 1] : 0.f);   // lfilter([1, -a], [1], x), zero state
+            return v * window[wi];
+        };
+        cplx v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = {sample(2 * c), sample(2 * c + 1)};
+        }
+        fft_pass1<false>(v, lds, lane);
+        __builtin_amdgcn_wave_barrier();
+        fft_load(v, lds, lane);
+        __builtin_amdgcn_wave_barrier();
+        fft_pass2<false>(v, lds, lane, T2);
+        __builtin_amdgcn_wave_barrier();
+        fft_load(v, lds, lane);
+        __builtin_amdgcn_wave_barrier();
+        fft_pass3<false>(v, lane, T3);
+#pragma unroll
+        for (int i = 8; i < 16; ++i) lds[fft_pad(lane + 64 * i)] = v[i];
+        __builtin_amdgcn_wave_barrier();
+        float* mrow = mag + (size_t)f * ldm;
+        float* lrow = lin ? lin + (size_t)f * nbins : nullptr;
+        auto emit = [&](int k, float a) {
+            mrow[k] = a;
+            if (lrow) lrow[k] = fminf(fmaxf((20.f * log10f(fmaxf(1e-5f, a)) - ref_db - min_db) / -min_db, 0.f), 1.f);
+        };
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = lane + 64 * j;
+            if (k == 0) {
+                emit(0, fabsf(v[0].x + v[0].y));
+                emit(FFT_N, fabsf(v[0].x - v[0].y));
+                emit(FFT_N / 2, sqrtf(v[8].x * v[8].x + v[8].y * v[8].y));
+            } else {
+                cplx Xk, Xn;
+                rfft_split(v[j], lds[fft_pad(FFT_N - k)], wk_s[k], Xk, Xn);
+                emit(k, sqrtf(Xk.x * Xk.x + Xk.y * Xk.y));
+                emit(FFT_N - k, sqrtf(Xn.x * Xn.x + Xn.y * Xn.y));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+void launch_stft_center(const GLPlan& p, const float* wav, int B, int n, int T, float preemph, float ref_db,
+                        float min_db, float* mag, int ldm, float* lin, hipStream_t s, Timing* tm) {
+    if (tm) tm->begin(KK_GL_ITER, s);
+    const long nframes = (long)B * T;
+    const int blocks = (int)std::min<long>((nframes + GL_WAVES - 1) / GL_WAVES, 2048);
+    const size_t lds = (size_t)(FFT_TW + FFT_N / 2 + GL_WAVES * FFT_LDS) * sizeof(cplx);
+    hipLaunchKernelGGL(stft_center_kernel, dim3(blocks), dim3(GL_THREADS), lds, s, wav, (const float2*)p.twiddle,
+                       p.window, B, n, T, p.hop, p.win, p.nbins, preemph, ref_db, min_db, mag, ldm, lin);
+    if (tm) tm->end(KK_GL_ITER, s);
+}
+
 // wav[b][g] = sum of the frames covering sample g (tf overlap_and_add), g < (T-1)*hop + win
 __global__ void gl_ola_kernel(const float* __restrict__ frames, float* __restrict__ wav, int B, int T, int hop, int win) {
     const long L = (long)(T - 1) * hop + win;

@@ -37,7 +37,9 @@ struct Timing {
 // ACT_HIGHWAY_FUSED: the whole highway layer in the epilogue. W's columns come in blocks of 64 = [32 H | 32 T] of the
 // same 32 units (so that one lane of the 32x32 MFMA layout holds H and T of a unit), R is the layer input x
 // [M, N/2], C the layer output y = relu(H) * sigmoid(T) + x * (1 - sigmoid(T)) [M, N/2] (modules.py:100-123).
-enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3, ACT_HIGHWAY_FUSED = 5 };
+// ACT_DB_NORM: clip((20 log10(max(1e-5, v)) - p0 - p1) / -p1, 0, 1) with p0 = ref_level_db, p1 = min_level_db
+// (tools/audio.py:78-79,217,264: amplitude -> dB -> normalised), for the mel projection of taco_spectrogram.
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3, ACT_HIGHWAY_FUSED = 5, ACT_DB_NORM = 6 };
 
 // C[m, n] = epi( sum_{j<taps} sum_{c<Cin} X[b, t+j-padl, c] * W[j*Cin+c, n] ), m = b*T + t.
 // epi(v) = ((act(v + bias[n])) * scale[n] + shift[n]) + R[m, n]   (absent pieces skipped)
@@ -63,6 +65,7 @@ struct GemmArgs {
     int ngroups;                  //   above are then ignored; all share Cin, N, ldw, act), or null
     float* partial;               // split-K scratch of splitk * M * roundup(N, 64) floats, or null
     int splitk;                   // > 1: K split over grid.z + a reduction/epilogue kernel (conv_gemm_pick_splitk)
+    float p0, p1;                 // activation parameters (ACT_DB_NORM)
 };
 int conv_gemm_pick_splitk(int M, int N, int nk);
 void launch_conv_gemm(const GemmArgs& a, hipStream_t s, Timing* tm);
@@ -151,5 +154,9 @@ void launch_gl_mag(const float* lin, float* mag, size_t n, float min_db, float r
 void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, float* frames_out, int B, int T,
                     int first, hipStream_t s, Timing* tm);
 void launch_gl_ola(const GLPlan& p, const float* frames, float* wav, int B, int T, hipStream_t s, Timing* tm);
+// Centred STFT analysis (librosa.stft of the pre-emphasised signal, tools/audio.py:37,119-134): wav [B, n] ->
+// frames T = 1 + n / hop; mag [B*T, ldm] = |D| (columns >= nbins untouched), lin [B*T, nbins] normalised dB or null.
+void launch_stft_center(const GLPlan& p, const float* wav, int B, int n, int T, float preemph, float ref_db,
+                        float min_db, float* mag, int ldm, float* lin, hipStream_t s, Timing* tm);
 
 }  // namespace taco

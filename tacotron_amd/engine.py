@@ -28,6 +28,10 @@ class TacoEngine:
         check_weights(weights, self.hp)
         self.device = torch.device('cuda', device)
         self._hp_struct = _lib.make_hparams_struct(self.hp)
+        weights = dict(weights)
+        if 'audio/mel_basis' not in weights:      # not a TF variable: derived from hparams (tools/audio.py:246-252)
+            from .tools.audio import build_mel_basis
+            weights['audio/mel_basis'] = build_mel_basis(self.hp)
         names = sorted(weights)
         arrays = [np.ascontiguousarray(weights[n], dtype=np.float32) for n in names]
         entries = (_lib.TacoWeightEntry * len(names))()
@@ -200,6 +204,29 @@ class TacoEngine:
                                               ws.data_ptr(), ws.numel(), self._s))
         self._leave()
         return wav[0] if squeeze else wav
+
+    def spectrogram(self, wav, want_linear=True, want_mel=True):
+        """Analysis side (tools/audio.py:23-42,66-79): wav [B, n] (or [n]) -> (linear [B, T, num_freq],
+        mel [B, T, num_mels]) normalised dB spectrograms, T = 1 + n // hop; either may be skipped (None)."""
+        wav = self._dev(wav, torch.float32)
+        if wav.dim() == 1:
+            wav = wav[None]
+        B, n = wav.shape
+        _, hop, _ = self.hp.stft_params()
+        T = 1 + n // hop
+        need = int(self.lib.taco_spectrogram_workspace_bytes(self.handle, B, n))
+        if need == 0:
+            raise TacoError('taco_spectrogram_workspace_bytes rejected B=%d n=%d' % (B, n))
+        ws = self._empty((need,), torch.uint8)
+        lin = self._empty((B, T, self.hp.num_freq), torch.float32) if want_linear else None
+        mel = self._empty((B, T, self.hp.num_mels), torch.float32) if want_mel else None
+        self._enter()
+        self._check(self.lib.taco_spectrogram(self.handle, wav.data_ptr(), B, n, float(self.hp.preemphasis),
+                                              lin.data_ptr() if lin is not None else None,
+                                              mel.data_ptr() if mel is not None else None,
+                                              ws.data_ptr(), ws.numel(), self._s))
+        self._leave()
+        return lin, mel
 
     def synthesize(self, ids, lens, max_iters=None, to_wav=False, gl_iters=None, out=None):
         """encode -> decode -> postnet [-> Griffin-Lim] in one C call. Returns a dict of device

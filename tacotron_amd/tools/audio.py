@@ -3,8 +3,10 @@
 Device side: `spectrogram_tensorflow_inv` (audio.py:57-64) runs the HIP Griffin-Lim
 (taco_griffin_lim). Host side, as in the reference (synthesizer.py:44-57): `pre_emphasis_inv`
 (audio.py:111-116), `find_endpoint` (audio.py:81-88), `save_wav` (audio.py:15-17).
-The analysis half of the reference module (load_wav, spectrogram, mel_spectrogram, ...) belongs
-to preprocessing and is out of scope."""
+Analysis half (audio.py:23-42,66-79: what data/data_load.py:114-146 stores as `*-spec-*.npy` / `*-mel-*.npy`):
+`spectrogram` / `mel_spectrogram` run the centred STFT, dB scaling and mel projection on the GPU
+(taco_spectrogram); `build_mel_basis` restates librosa.filters.mel (librosa 0.5.1: Slaney scale, area-normalised)
+on the host - librosa is not installed here, so that restatement is unpinned. load_wav / trim_silence stay out."""
 import wave
 
 import numpy as np
@@ -23,6 +25,51 @@ inv_spectrogram = spectrogram_tensorflow_inv
 
 def _db_to_amp(x):
     return np.power(10.0, x * 0.05)
+
+
+def _hz_to_mel(f):
+    """librosa.hz_to_mel(htk=False): linear below 1 kHz (200/3 Hz per mel), logarithmic above (Slaney)."""
+    f = np.asarray(f, np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, f / f_sp)
+
+
+def _mel_to_hz(m):
+    m = np.asarray(m, np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def build_mel_basis(hp=None):
+    """audio.py:246-252: librosa.filters.mel(sample_rate, n_fft, n_mels=num_mels) -> [num_mels, 1 + n_fft/2]
+    (fmin 0, fmax sr/2, htk=False, norm=1: triangles on the Slaney mel scale, each scaled by 2 / its bandwidth)."""
+    hp = hp or hparams
+    sr, n_fft, n_mels = float(hp.sample_rate), int(hp.n_fft), int(hp.num_mels)
+    fftfreqs = np.linspace(0.0, sr / 2, 1 + n_fft // 2)
+    mel_f = _mel_to_hz(np.linspace(_hz_to_mel(0.0), _hz_to_mel(sr / 2), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    lower = -ramps[:-2] / fdiff[:-1, None]
+    upper = ramps[2:] / fdiff[1:, None]
+    weights = np.maximum(0.0, np.minimum(lower, upper))
+    weights *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return weights.astype(np.float32)
+
+
+def spectrogram(y, engine):
+    """audio.py:23-42: normalised linear-scale dB spectrogram [1 + n_fft/2, frames] of one waveform."""
+    lin, _ = engine.spectrogram(np.asarray(y, np.float32)[None], want_mel=False)
+    return lin[0].T.cpu().numpy()
+
+
+def mel_spectrogram(y, engine):
+    """audio.py:66-79: normalised mel-scale dB spectrogram [num_mels, frames]."""
+    _, mel = engine.spectrogram(np.asarray(y, np.float32)[None], want_linear=False)
+    return mel[0].T.cpu().numpy()
 
 
 def pre_emphasis_inv(x, coef=None):

@@ -137,3 +137,24 @@ def test_fft_core_host_emulation():
     subprocess.run(['g++', '-O2', '-o', exe, os.path.join(HERE, 'host', 'fft_host_test.cpp')], check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_mel_basis_restatements_agree():
+    """tools.audio.build_mel_basis (product, vectorised) against the oracle's filter-by-filter formulation of
+    librosa.filters.mel (Slaney scale, area normalisation). Both come from library knowledge: unpinned."""
+    from tacotron_amd.hparams import HParams
+    from tacotron_amd.tools.audio import build_mel_basis
+    hp = HParams()
+    a = build_mel_basis(hp)
+    b = O.mel_basis_librosa(hp.sample_rate, hp.n_fft, hp.num_mels)
+    assert a.shape == (80, 1025) and a.dtype == np.float32
+    assert np.abs(a - b).max() < 1e-8
+    assert (a >= 0).all() and (a.sum(1) > 0).all() and a[:, 0].sum() == 0
+    # Slaney normalisation: every triangle has (approximately, on the FFT grid) unit area in Hz
+    hz_per_bin = hp.sample_rate / hp.n_fft
+    assert np.allclose(a.sum(1) * hz_per_bin, 1.0, atol=0.15)
+
+
+def test_pre_emphasis_roundtrip():
+    x = np.random.default_rng(0).standard_normal(1000)
+    assert np.allclose(O.pre_emphasis_inv(O.pre_emphasis(x, 0.97), 0.97), x, atol=1e-9)

@@ -328,3 +328,29 @@ def test_decode_teacher_forced(engine, hp, weights, B, T_in, T_out):
     # and it differs from the free-running decode of the same memory (the targets are really fed)
     mel_f, _, _ = engine.decode(enc.astype(np.float32), max_iters=steps_r)
     assert rel_l1(_np(mel_f), mel_r) > 1e-3
+
+
+@pytest.mark.parametrize('n', [3001, 24000])
+def test_spectrogram_analysis(engine, hp, n):
+    """Analysis side (tools/audio.py:23-42,66-79): centred STFT of the pre-emphasised signal, dB, normalisation, mel
+    projection, against the oracle's float64 restatement of librosa's stft / filters.mel. Values are in [0, 1]
+    (1 unit = 100 dB): absolute tolerance; bins the clip at 0 silences compare as equal."""
+    rng = np.random.default_rng(n)
+    t = np.arange(n) / hp.sample_rate
+    y = 0.3 * np.sin(2 * np.pi * 440.0 * t) * np.hanning(n) + 0.02 * rng.standard_normal(n)
+    lin_r = O.spectrogram_librosa(y, hp).T
+    mel_r = O.mel_spectrogram_librosa(y, hp).T
+    lin, mel = engine.spectrogram(y.astype(np.float32))
+    lin, mel = _np(lin)[0], _np(mel)[0]
+    assert lin.shape == lin_r.shape == (1 + n // 300, 1025) and mel.shape == mel_r.shape == (1 + n // 300, 80)
+    assert lin_r.max() > 0.5 and mel_r.max() > 0.5            # a real signal, not all clipped
+    assert max_abs(lin, lin_r) < 2e-3 and max_abs(mel, mel_r) < 2e-3
+    assert rel_l1(lin, lin_r) < 1e-4 and rel_l1(mel, mel_r) < 1e-4
+    # batch of two equal-length signals, one output skipped
+    y2 = np.stack([y, y[::-1]]).astype(np.float32)
+    lin2, none = engine.spectrogram(y2, want_mel=False)
+    assert none is None and np.array_equal(_np(lin2)[0], lin)
+    # tools.audio mirrors the reference's [freq, T] orientation
+    from tacotron_amd.tools import audio
+    assert audio.spectrogram(y, engine).shape == (1025, 1 + n // 300)
+    assert audio.mel_spectrogram(y, engine).shape == (80, 1 + n // 300)
