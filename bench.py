@@ -156,8 +156,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world > 1:
+        # one rank per GPU over RCCL. TACO_BENCH_BACKEND=gloo (rehearsal of the multi-rank path on a box with fewer
+        # GPUs than ranks: the ranks then share devices round-robin) is for testing only.
+        backend = os.environ.get('TACO_BENCH_BACKEND', 'nccl')
+        ndev = torch.cuda.device_count()
+        if backend == 'nccl' and local >= ndev:
+            raise SystemExit('rank %d: LOCAL_RANK %d but only %d GPUs visible' % (rank, local, ndev))
+        local = local % max(ndev, 1)
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     hp = HParams()
     hp.max_iters = args.max_iters
     weights = init_weights(hp, seed=1234)          # "random-init weights" (BASELINE.json configs)
@@ -218,7 +228,7 @@ def main():
             live_n += n_
             live_ms += ms_
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=eng.device)
+        t = torch.tensor([el], dtype=torch.float64, device=eng.device if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     steps_run = int(out['steps'].item())
