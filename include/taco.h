@@ -138,6 +138,17 @@ int taco_postnet(taco_handle h, const float* mel, int32_t B, int32_t T, float* l
 int taco_griffin_lim(taco_handle h, const float* linear, int32_t B, int32_t T, int32_t iters,
                      float* wav, void* ws, size_t ws_bytes, taco_stream_t stream);
 
+/* tools/audio.py:44-55 spectrogram_inv up to, not including, pre_emphasis_inv (host): the
+ * numpy/librosa flavour of Griffin-Lim (audio.py:167-181) that train.py uses for its evaluation
+ * audio: centred, reflect-padded librosa.stft (audio.py:119-134) and librosa.istft with
+ * window-sum-square normalisation (audio.py:136-148), phases exp(i angle(.)) (unit phase at 0).
+ * phase_u [B,T,num_freq] holds the uniform [0,1) draws of audio.py:175 (np.random.rand, here
+ * frame-major) or is NULL for zero initial phase.  linear [B,T,num_freq] -> wav [B,hop*(T-1)].
+ * Needs hop*(T-1) > n_fft/2.  Workspace: as taco_griffin_lim (taco_workspace_bytes). */
+int taco_griffin_lim_librosa(taco_handle h, const float* linear, const float* phase_u, int32_t B,
+                             int32_t T, int32_t iters, float* wav, void* ws, size_t ws_bytes,
+                             taco_stream_t stream);
+
 /* Analysis side, what data/data_load.py:114-146 computes per utterance with tools/audio.py:23-42,66-79:
  *   D = librosa.stft(pre_emphasis(wav), n_fft, hop, win, 'hann')   (centred, reflect-padded; audio.py:37,109,119-134)
  *   linear = normalize(20 log10(max(1e-5, |D|)) - ref_level_db)               [B, T, num_freq]   (audio.py:40-42)

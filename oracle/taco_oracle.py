@@ -378,18 +378,24 @@ def istft_librosa(X, hop, win):
     return y[n_fft // 2:-(n_fft // 2)]
 
 
-def spectrogram_inv_librosa(spect, hp, rng):
-    """audio.py:44-55 on [1025, T]; `rng` replaces the reference's unseeded np.random.rand."""
+def griffin_lim_librosa(spect, hp, u, iters=None):
+    """audio.py:53,167-181 on [1025, T]: `u` [1025, T] are the uniform draws of np.random.rand (audio.py:175)."""
     n_fft, hop, win = hp.stft_params()
+    iters = hp.griffin_lim_iters if iters is None else iters
     S = np.power(10.0, ((np.clip(spect, 0, 1) * -float(hp.min_level_db)) + hp.min_level_db + hp.ref_level_db) * 0.05)
     S = S ** hp.power
-    ang = np.exp(2j * np.pi * rng.random(S.shape))
+    ang = np.exp(2j * np.pi * u)
     Sc = np.abs(S).astype(complex)
     y = istft_librosa(Sc * ang, hop, win)
-    for _ in range(hp.griffin_lim_iters):
+    for _ in range(iters):
         ang = np.exp(1j * np.angle(stft_librosa(y, n_fft, hop, win)))
         y = istft_librosa(Sc * ang, hop, win)
-    return pre_emphasis_inv(y, hp.preemphasis)
+    return y
+
+
+def spectrogram_inv_librosa(spect, hp, rng, iters=None):
+    """audio.py:44-55 on [1025, T]; `rng` replaces the reference's unseeded np.random.rand."""
+    return pre_emphasis_inv(griffin_lim_librosa(spect, hp, rng.random(spect.shape), iters), hp.preemphasis)
 
 
 # ----------------------------------------------------------------------------------------

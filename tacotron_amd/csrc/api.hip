@@ -1042,6 +1042,43 @@ static int gl_impl(taco_ctx* c, const float* linear, int B, int T, int iters, fl
     return 0;
 }
 
+// numpy/librosa flavour (audio.py:44-55,167-181) up to, not including, pre_emphasis_inv
+static int gl_librosa_impl(taco_ctx* c, const float* linear, const float* phase_u, int B, int T, int iters, float* wav,
+                           Carver& ws, hipStream_t s) {
+    Timing* tm = c->timing_on ? &c->timing : nullptr;
+    const TacoHParams& hp = c->hp;
+    const size_t M = (size_t)B * T;
+    float* mag = ws.take<float>(M * hp.num_freq);
+    float* fa = ws.take<float>(M * hp.win_length);
+    float* fb = ws.take<float>(M * hp.win_length);
+    if (!ws.ok()) return fail("taco_griffin_lim_librosa: workspace too small");
+    GLPlan p{hp.n_fft, hp.hop_length, hp.win_length, hp.num_freq, c->twiddle, c->window};
+    launch_gl_mag(linear, mag, M * hp.num_freq, hp.min_level_db, hp.ref_level_db, hp.power, s, tm);
+    launch_gl_iter(p, fa, mag, fa, B, T, 1, s, tm, true, phase_u);   // y = istft(S * angles) (audio.py:175-177)
+    float* cur = fa;
+    float* nxt = fb;
+    for (int i = 0; i < iters; ++i) {                                // audio.py:178-180
+        launch_gl_iter(p, cur, mag, nxt, B, T, 0, s, tm, true, nullptr);
+        std::swap(cur, nxt);
+    }
+    launch_gl_ola_norm(p, cur, wav, B, T, s, tm);
+    return 0;
+}
+
+extern "C" int taco_griffin_lim_librosa(taco_handle h, const float* linear, const float* phase_u, int32_t B, int32_t T,
+                                        int32_t iters, float* wav, void* ws, size_t ws_bytes, taco_stream_t stream) {
+    if (!h || !linear || !wav || !ws) return fail("taco_griffin_lim_librosa: null argument");
+    if (check_dims(B, T)) return -1;
+    if (iters < 0) return fail("taco_griffin_lim_librosa: iters < 0");
+    if ((long)h->hp.hop_length * (T - 1) <= h->hp.n_fft / 2)
+        return fail("taco_griffin_lim_librosa: need hop*(T-1) > n_fft/2 samples (reflect padding of the centred STFT), "
+                    "got T = %d", T);
+    HIP_OK(hipSetDevice(h->device));
+    Carver cv(ws, ws_bytes);
+    if (gl_librosa_impl(h, linear, phase_u, B, T, iters, wav, cv, (hipStream_t)stream)) return -1;
+    return check_launch("taco_griffin_lim_librosa");
+}
+
 // ---------------------------------------------------------------------------------------
 extern "C" size_t taco_spectrogram_workspace_bytes(taco_handle h, int32_t B, int32_t n_samples) {
     if (!h || B < 1 || n_samples < 1) return 0;

@@ -41,12 +41,48 @@ constexpr int GL_THREADS = 256;
 constexpr int GL_WAVES = 4;
 constexpr int GL_RUN = 16;          // consecutive frames per workgroup (upper bound; the launcher may lower it)
 
+// Sample g (frame coordinates: frame m covers [hop m, hop m + win)) of the window-sum-square normalised overlap-add
+// of librosa's istft (the oracle's istft_librosa): sum of the covering frames / sum of their squared windows.
+__device__ __forceinline__ float gl_ola_norm(const float* __restrict__ frames_u, const float* __restrict__ w, int g,
+                                             int T, int hop, int win, int nover) {
+    const int q = g / hop;
+    const int mhi = min(T - 1, q);
+    const int mlo = max(0, q - (nover - 1));
+    float s = 0.f, ws = 0.f;
+    for (int m2 = mlo; m2 <= mhi; ++m2) {
+        const int off = g - hop * m2;
+        if (off < win) {
+            s += frames_u[(long)m2 * win + off];
+            ws += w[off] * w[off];
+        }
+    }
+    return ws > 1.17549435e-38f ? s / ws : s;       // util.tiny(float32)
+}
+
+// np.exp(1j * np.angle(X)) * mag (audio.py:179-180): unit phase where X == 0
+__device__ __forceinline__ cplx gl_rephase_np(cplx X, float mag) {
+    const float a = sqrtf(X.x * X.x + X.y * X.y);
+    if (!(a > 0.f)) return {mag, 0.f};
+    const float s = mag / a;
+    return {X.x * s, X.y * s};
+}
+
+// LIBROSA = false: the TF graph of audio.py:183-205 (see the head of this file).
+// LIBROSA = true: the numpy/librosa loop of audio.py:167-181 on the same frame FFT. librosa's frames are n_fft long
+// with the Hann window centred in them, i.e. the TF frame shifted by lp = (n_fft - win)/2 samples: X_lib[k] =
+// W^(lp k) X_tf[k], and the inverse takes Y_tf[k] = Y_lib[k] conj(W^(lp k)), so inside the loop the rotation cancels
+// and only three things differ: the signal between iterations is the overlap-add divided by the window-sum-square and
+// trimmed to [win/2, win/2 + hop (T-1)) in frame coordinates, the frames of the next analysis read it through
+// np.pad(mode='reflect'), and the first synthesis starts from caller-supplied random phases exp(2 pi i u) (rotated by
+// conj(W^(lp k))) instead of zero phase. first: 0 = iteration, 1 = first synthesis.
 // LDS: [y segment: (run-1)*hop + win floats][window: win floats][twiddle tables: FFT_TW + 512 cplx][4 x FFT_LDS cplx]
+template <bool LIBROSA>
 __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __restrict__ frames_in,
                                                              const float* __restrict__ mag,
                                                              float* __restrict__ frames_out,
                                                              const float2* __restrict__ twiddle,
-                                                             const float* __restrict__ window, int B, int T, int hop,
+                                                             const float* __restrict__ window,
+                                                             const float* __restrict__ phase_u, int B, int T, int hop,
                                                              int win, int nbins, int first, int run, int runs_per_utt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gl_smem[];
     const int seg_cap = (run - 1) * hop + win;
@@ -71,7 +107,19 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __r
     for (int i = tid; i < win; i += GL_THREADS) win_s[i] = window[i];
     for (int e = tid; e < FFT_TW; e += GL_THREADS) tw_s[e] = fft_tw_entry(e, Wt);
     for (int e = tid; e < FFT_N / 2; e += GL_THREADS) wk_s[e] = Wt[e];
-    if (!first) {
+    if (LIBROSA && !first) {
+        // ---- the samples the run covers, read through the trim and the reflect padding:
+        // padded position hop*m0 + i is sample j = hop*m0 + i - win/2 of y (length hop (T-1)), reflected at its ends
+        __syncthreads();                               // win_s
+        const int seg = (nfr - 1) * hop + win;
+        const int L = hop * (T - 1), ctr = win >> 1;
+        for (int i = tid; i < seg; i += GL_THREADS) {
+            int j = hop * m0 + i - ctr;
+            if (j < 0) j = -j;
+            if (j >= L) j = 2 * (L - 1) - j;
+            yseg[i] = gl_ola_norm(frames_in + fb * win, win_s, j + ctr, T, hop, win, nover);
+        }
+    } else if (!first) {
         // ---- the samples the run covers: y[hop*m0 + i] = sum of the covering frames of the previous iteration
         const int seg = (nfr - 1) * hop + win;
         for (int i = 2 * tid; i < seg; i += 2 * GL_THREADS) {
@@ -135,32 +183,47 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __r
             __builtin_amdgcn_wave_barrier();
         }
         // ---- split -> re-phase against mag -> merge on the bin pairs (k, 1024 - k), k = lane + 64 j
+        const float* pu = LIBROSA && phase_u ? phase_u + f * nbins : nullptr;
+        const int lp = FFT_N - (win >> 1);            // (n_fft - win) / 2
+        auto rephase = [](cplx X, float m) -> cplx { return LIBROSA ? gl_rephase_np(X, m) : gl_rephase(X, m); };
+        // first synthesis of the librosa loop: mag * exp(2 pi i u[k]) * conj(W^(lp k)), W = exp(-2 pi i / n_fft)
+        auto start = [&](float m, int k) -> cplx {
+            const float rot = (float)((lp * k) & (2 * FFT_N - 1)) * (1.f / (2 * FFT_N));
+            float sn, cs;
+            sincospif(2.f * ((pu ? pu[k] : 0.f) + rot), &sn, &cs);
+            return {m * cs, m * sn};
+        };
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = lane + 64 * j;
             if (k == 0) {
                 // bins 0 and 1024 are real: X0 = Re Z0 + Im Z0, X1024 = Re Z0 - Im Z0
                 float y0, yn;
-                if (first) { y0 = mk[0]; yn = mn[0]; }
-                else {
-                    y0 = gl_rephase({v[0].x + v[0].y, 0.f}, mk[0]).x;
-                    yn = gl_rephase({v[0].x - v[0].y, 0.f}, mn[0]).x;
+                if (first) {
+                    // (irfft drops the imaginary parts of bins 0 and n_fft/2; their rotation is 1)
+                    y0 = LIBROSA ? start(mk[0], 0).x : mk[0];
+                    yn = LIBROSA ? start(mn[0], FFT_N).x : mn[0];
+                } else {
+                    y0 = rephase({v[0].x + v[0].y, 0.f}, mk[0]).x;
+                    yn = rephase({v[0].x - v[0].y, 0.f}, mn[0]).x;
                 }
                 v[0] = {0.5f * (y0 + yn), 0.5f * (y0 - yn)};
                 // bin 512 pairs with itself: X512 = conj(Z512); Z'512 = conj(Y512)
                 cplx ym;
-                if (first) ym = {m512, 0.f};
-                else ym = gl_rephase(cconj(v[8]), m512);
+                if (first) ym = LIBROSA ? start(m512, FFT_N / 2) : cplx{m512, 0.f};
+                else ym = rephase(cconj(v[8]), m512);
                 lds[fft_pad(FFT_N / 2)] = cconj(ym);
             } else {
                 const cplx Wk = wk_s[k];
                 cplx Yk, Yn;
-                if (first) { Yk = {mk[j], 0.f}; Yn = {mn[j], 0.f}; }
-                else {
+                if (first) {
+                    if (LIBROSA) { Yk = start(mk[j], k); Yn = start(mn[j], FFT_N - k); }
+                    else { Yk = {mk[j], 0.f}; Yn = {mn[j], 0.f}; }
+                } else {
                     cplx Xk, Xn;
                     rfft_split(v[j], lds[fft_pad(FFT_N - k)], Wk, Xk, Xn);
-                    Yk = gl_rephase(Xk, mk[j]);
-                    Yn = gl_rephase(Xn, mn[j]);
+                    Yk = rephase(Xk, mk[j]);
+                    Yn = rephase(Xn, mn[j]);
                 }
                 cplx Zk, Zn;
                 irfft_merge(Yk, Yn, Wk, Zk, Zn);
@@ -196,7 +259,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __r
 }
 
 void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, float* frames_out, int B, int T,
-                    int first, hipStream_t s, Timing* tm) {
+                    int first, hipStream_t s, Timing* tm, bool librosa, const float* phase_u) {
     if (tm) tm->begin(KK_GL_ITER, s);
     // frames per workgroup: as many as keep the y segment within ~24 KB of LDS (2 workgroups per CU and more)
     int run = GL_RUN;
@@ -207,13 +270,21 @@ void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, f
     static bool attr_set[64] = {};   // more than the default 64 KB of dynamic LDS: the attribute is per device
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(gl_iter_kernel, dim3((unsigned)(B * runs_per_utt)), dim3(GL_THREADS), lds, s, frames_in, mag,
-                       frames_out, (const float2*)p.twiddle, p.window, B, T, p.hop, p.win, p.nbins, first, run,
-                       runs_per_utt);
+    const dim3 grid((unsigned)(B * runs_per_utt));
+    if (librosa)
+        hipLaunchKernelGGL(gl_iter_kernel<true>, grid, dim3(GL_THREADS), lds, s, frames_in, mag, frames_out,
+                           (const float2*)p.twiddle, p.window, phase_u, B, T, p.hop, p.win, p.nbins, first, run,
+                           runs_per_utt);
+    else
+        hipLaunchKernelGGL(gl_iter_kernel<false>, grid, dim3(GL_THREADS), lds, s, frames_in, mag, frames_out,
+                           (const float2*)p.twiddle, p.window, phase_u, B, T, p.hop, p.win, p.nbins, first, run,
+                           runs_per_utt);
     if (tm) tm->end(KK_GL_ITER, s);
 }
 
@@ -325,6 +396,28 @@ __global__ void gl_ola_kernel(const float* __restrict__ frames, float* __restric
         }
         wav[i] = s;
     }
+}
+
+// librosa istft output (the oracle's istft_librosa): wav[b][j] = normalised overlap-add at frame coordinate j + win/2,
+// j < hop (T-1)
+__global__ void gl_ola_norm_kernel(const float* __restrict__ frames, const float* __restrict__ window,
+                                   float* __restrict__ wav, int B, int T, int hop, int win) {
+    const long L = (long)(T - 1) * hop;
+    const int nover = (win + hop - 1) / hop;
+    const long total = (long)B * L;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / L);
+        const int j = (int)(i - (long)b * L);
+        wav[i] = gl_ola_norm(frames + (long)b * T * win, window, j + (win >> 1), T, hop, win, nover);
+    }
+}
+
+void launch_gl_ola_norm(const GLPlan& p, const float* frames, float* wav, int B, int T, hipStream_t s, Timing* tm) {
+    if (tm) tm->begin(KK_GL_OLA, s);
+    const long total = (long)B * (long)(T - 1) * p.hop;
+    const int blocks = (int)std::min<long>(4096, (total + 255) / 256);
+    hipLaunchKernelGGL(gl_ola_norm_kernel, dim3(blocks), dim3(256), 0, s, frames, p.window, wav, B, T, p.hop, p.win);
+    if (tm) tm->end(KK_GL_OLA, s);
 }
 
 void launch_gl_ola(const GLPlan& p, const float* frames, float* wav, int B, int T, hipStream_t s, Timing* tm) {

@@ -150,10 +150,14 @@ struct GLPlan {
 };
 void launch_gl_mag(const float* lin, float* mag, size_t n, float min_db, float ref_db, float power,
                    hipStream_t s, Timing* tm);
-// frames_in/out [B*T][win]; first != 0: inverse of (mag, zero phase) only.
+// frames_in/out [B*T][win]; first != 0: inverse of (mag, zero phase) only. librosa: the numpy/librosa flavour of the
+// loop (normalised, trimmed, reflect-padded signal between iterations; first synthesis from the phases
+// exp(2 pi i phase_u), phase_u [B*T][nbins] or null = zero phase).
 void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, float* frames_out, int B, int T,
-                    int first, hipStream_t s, Timing* tm);
+                    int first, hipStream_t s, Timing* tm, bool librosa = false, const float* phase_u = nullptr);
 void launch_gl_ola(const GLPlan& p, const float* frames, float* wav, int B, int T, hipStream_t s, Timing* tm);
+// librosa.istft's output: wav [B][hop (T-1)], window-sum-square normalised, n_fft/2 trimmed from both ends
+void launch_gl_ola_norm(const GLPlan& p, const float* frames, float* wav, int B, int T, hipStream_t s, Timing* tm);
 // Centred STFT analysis (librosa.stft of the pre-emphasised signal, tools/audio.py:37,119-134): wav [B, n] ->
 // frames T = 1 + n / hop; mag [B*T, ldm] = |D| (columns >= nbins untouched), lin [B*T, nbins] normalised dB or null.
 void launch_stft_center(const GLPlan& p, const float* wav, int B, int n, int T, float preemph, float ref_db,

@@ -205,6 +205,29 @@ class TacoEngine:
         self._leave()
         return wav[0] if squeeze else wav
 
+    def griffin_lim_librosa(self, linear, phase_u=None, iters=None):
+        """tools/audio.py:44-55,167-181 without the final pre_emphasis_inv: linear [B, T, num_freq] (or [T, num_freq])
+        normalised spectrogram, phase_u same shape of uniform [0, 1) draws (None = zero phase) ->
+        wav [B, hop * (T - 1)]."""
+        linear = self._dev(linear, torch.float32)
+        squeeze = linear.dim() == 2
+        if squeeze:
+            linear = linear[None]
+        B, T, _ = linear.shape
+        if phase_u is not None:
+            phase_u = self._dev(phase_u, torch.float32).reshape(linear.shape)
+        iters = self.hp.griffin_lim_iters if iters is None else int(iters)
+        _, hop, win = self.hp.stft_params()
+        S = -(-T // self.hp.outputs_per_step)
+        ws = self._workspace(B, 1, S)
+        wav = self._empty((B, (T - 1) * hop,), torch.float32)
+        self._enter()
+        self._check(self.lib.taco_griffin_lim_librosa(self.handle, linear.data_ptr(),
+                                                      phase_u.data_ptr() if phase_u is not None else None, B, T, iters,
+                                                      wav.data_ptr(), ws.data_ptr(), ws.numel(), self._s))
+        self._leave()
+        return wav[0] if squeeze else wav
+
     def spectrogram(self, wav, want_linear=True, want_mel=True):
         """Analysis side (tools/audio.py:23-42,66-79): wav [B, n] (or [n]) -> (linear [B, T, num_freq],
         mel [B, T, num_mels]) normalised dB spectrograms, T = 1 + n // hop; either may be skipped (None)."""

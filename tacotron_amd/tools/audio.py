@@ -2,7 +2,8 @@
 
 Device side: `spectrogram_tensorflow_inv` (audio.py:57-64) runs the HIP Griffin-Lim
 (taco_griffin_lim). Host side, as in the reference (synthesizer.py:44-57): `pre_emphasis_inv`
-(audio.py:111-116), `find_endpoint` (audio.py:81-88), `save_wav` (audio.py:15-17).
+(audio.py:111-116), `find_endpoint` (audio.py:81-88), `save_wav` (audio.py:15-17). `spectrogram_inv` (audio.py:44-55,
+the numpy/librosa Griffin-Lim train.py uses for evaluation audio) runs taco_griffin_lim_librosa.
 Analysis half (audio.py:23-42,66-79: what data/data_load.py:114-146 stores as `*-spec-*.npy` / `*-mel-*.npy`):
 `spectrogram` / `mel_spectrogram` run the centred STFT, dB scaling and mel projection on the GPU
 (taco_spectrogram); `build_mel_basis` restates librosa.filters.mel (librosa 0.5.1: Slaney scale, area-normalised)
@@ -21,6 +22,18 @@ def spectrogram_tensorflow_inv(spect, engine, iters=None):
 
 
 inv_spectrogram = spectrogram_tensorflow_inv
+
+
+def spectrogram_inv(spect, engine, iters=None, rng=None):
+    """audio.py:44-55: [num_freq, T] normalised linear spectrogram (the reference passes `spectrogram.T`) -> waveform
+    [hop * (T - 1)] float64, numpy/librosa-flavoured Griffin-Lim on the GPU (taco_griffin_lim_librosa) and the
+    de-emphasis on the host. The initial phases are np.random.rand(*spect.shape) as at audio.py:175 (global numpy
+    state, so np.random.seed reproduces the reference's draw), or rng.random(spect.shape) when a Generator is given."""
+    spect = np.asarray(spect)
+    u = np.random.rand(*spect.shape) if rng is None else rng.random(spect.shape)
+    y = engine.griffin_lim_librosa(np.ascontiguousarray(spect.T, np.float32), np.ascontiguousarray(u.T, np.float32),
+                                   iters)
+    return pre_emphasis_inv(y.cpu().numpy())
 
 
 def _db_to_amp(x):

@@ -257,6 +257,40 @@ def test_griffin_lim(engine, hp, B, T, iters):
     assert l2(got, ref) < (1e-5 if iters <= 1 else 1e-3)
 
 
+@pytest.mark.parametrize('B,T,iters,zero_phase', [(1, 6, 0, False), (2, 9, 1, False), (2, 37, 3, False), (1, 20, 2, True),
+                                                  (1, 50, 60, False)])
+def test_griffin_lim_librosa(engine, hp, B, T, iters, zero_phase):
+    """The numpy/librosa Griffin-Lim (audio.py:44-55,167-181; taco_griffin_lim_librosa) vs the fp64 oracle on the
+    same uniform phase draws, incl. runs that straddle both reflected ends (T = 6: every frame reads reflected
+    samples) and a ragged last run (T = 37). Same conditioning caveat as test_griffin_lim."""
+    rng = np.random.default_rng(100 + T + iters)
+    lin = rng.uniform(0.3, 1.0, size=(B, T, 1025)).astype(np.float32)
+    u = np.zeros((B, T, 1025)) if zero_phase else rng.random((B, T, 1025))
+    ref = np.stack([O.griffin_lim_librosa(lin[b].T.astype(np.float64), hp, u[b].T, iters) for b in range(B)])
+    got = _np(engine.griffin_lim_librosa(lin, None if zero_phase else u.astype(np.float32), iters=iters))
+    assert got.shape == ref.shape == (B, (T - 1) * 300)
+    l2 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    print('GL librosa T=%d iters=%d: gpu-vs-f64 relL2 %.2e' % (T, iters, l2))
+    assert l2 < (2e-5 if iters <= 1 else 1e-3)
+
+
+def test_spectrogram_inv_tool(engine, hp):
+    """tools.audio.spectrogram_inv (audio.py:44-55): global numpy seed -> same draws as the oracle, de-emphasis on
+    the host; and too-short inputs are refused (reflect padding needs hop (T-1) > n_fft/2)."""
+    from tacotron_amd.tools import audio
+    rng = np.random.default_rng(5)
+    spect = rng.uniform(0.3, 1.0, size=(1025, 12))
+    np.random.seed(1234)
+    got = audio.spectrogram_inv(spect, engine, iters=2)
+    np.random.seed(1234)
+    u = np.random.rand(1025, 12)
+    ref = O.pre_emphasis_inv(O.griffin_lim_librosa(spect, hp, u, 2), hp.preemphasis)
+    assert got.shape == ref.shape == (11 * 300,)
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-3
+    with pytest.raises(RuntimeError):
+        engine.griffin_lim_librosa(spect.T[:4].astype(np.float32), None, iters=1)
+
+
 def test_synthesize_end_to_end(engine, hp, weights):
     """ids -> mel, linear, alignments through taco_synthesize vs the oracle end to end (1e-3, north_star)."""
     rng = np.random.default_rng(42)
