@@ -112,3 +112,17 @@ def test_batch_and_pad():
     assert b.get_size() == 2 and b.get_all()[2] is None and b.get_input_lengths() is lens
     with pytest.raises(NotImplementedError):
         Batch([], prep=True)
+
+
+def test_split_text_and_plot(tmp_path):
+    from tacotron_amd.synthesizer import split_text
+    from tacotron_amd.tools.plot import plot_alignment
+    assert split_text('One. Two!  Three? four') == ['One.', 'Two!', 'Three?', 'four']
+    long = 'alpha beta, ' * 30 + 'omega.'
+    pieces = split_text(long, max_chars=50)
+    assert all(0 < len(p) <= 50 for p in pieces) and ' '.join(pieces) == long.strip()
+    assert split_text('x' * 120, max_chars=50) == ['x' * 50, 'x' * 50, 'x' * 20]
+    assert split_text('   ') == []
+    path = str(tmp_path / 'a.png')
+    plot_alignment(np.random.default_rng(0).random((20, 30)), path, info='step 7')
+    assert open(path, 'rb').read(4) == b'\x89PNG'

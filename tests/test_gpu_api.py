@@ -193,3 +193,53 @@ def test_griffin_lim_full_length(engine, hp):
     wav = audio.pre_emphasis_inv(_np(audio.inv_spectrogram(lin, engine)))
     assert wav.shape == (300900,) and np.isfinite(wav).all()
     assert 0 < audio.find_endpoint(wav) <= len(wav)
+
+
+def test_pipeline_in_flight_matches_lone_engine(engine, hp, weights):
+    """SynthesisPipeline: 5 different batches through 3 engines in flight come back in order and bit-identical to the
+    same batches run one at a time (no kernel's reduction order depends on what else is running)."""
+    from tacotron_amd.pipeline import SynthesisPipeline
+    rng = np.random.default_rng(77)
+    batches = [synth_ids(rng, B, T_in) for B, T_in in [(3, 20), (1, 33), (4, 12), (2, 20), (3, 27)]]
+    S = 7
+    pipe = SynthesisPipeline(weights, hp, depth=3)
+    try:
+        got = list(pipe.run(iter(batches), max_iters=S, to_wav=True, gl_iters=2))
+    finally:
+        pipe.close()
+    assert len(got) == len(batches)
+    for (ids, lens), o in zip(batches, got):
+        ref = engine.finish(engine.synthesize(ids, lens, max_iters=S, to_wav=True, gl_iters=2), to_wav=True, gl_iters=2)
+        assert o['steps_run'] == ref['steps_run'] == S
+        for name in ('mel', 'linear', 'alignments', 'wav'):
+            assert np.array_equal(o[name].numpy(), _np(ref[name])), name
+
+
+def test_synthesizer_extensions(tmp_path):
+    """synthesize_long (split + one batch + join), synthesize_many (pipeline, input order kept), plot=True."""
+    from tacotron_amd import synthesizer as S
+    from tacotron_amd.hparams import hparams
+    old = hparams.max_iters, hparams.griffin_lim_iters
+    hparams.max_iters, hparams.griffin_lim_iters = 6, 2
+    try:
+        s = S.Synthesizer().load_random(seed=3)
+        text = 'First sentence here. And a second one! Is there a third?'
+        pieces = S.split_text(text)
+        assert pieces == ['First sentence here.', 'And a second one!', 'Is there a third?']
+        singles = s.synthesize_batch(pieces)
+        long = s.synthesize_long(text, pause_s=0.01)
+        assert len(long) == sum(len(w) for w in singles) + 2 * int(0.01 * hparams.sample_rate)
+        assert np.array_equal(long[:len(singles[0])], singles[0])
+        texts = ['text number %d' % i for i in range(7)]
+        many = list(s.synthesize_many(texts, batch_size=3, depth=2))
+        assert [t for t, _ in many] == texts
+        # batch composition does not change an utterance's result beyond padding effects: same text alone
+        alone = s.synthesize_batch([texts[4]])[0]
+        assert many[4][1].shape == alone.shape and np.allclose(many[4][1], alone, atol=1e-4)
+        d = str(tmp_path / 'synthesized')
+        os.makedirs(d)
+        s.synthesize('plot me', d, plot=True)
+        png = os.path.join(d, 'alignments', 'align-001.png')
+        assert os.path.getsize(png) > 1000 and open(png, 'rb').read(4) == b'\x89PNG'
+    finally:
+        hparams.max_iters, hparams.griffin_lim_iters = old
