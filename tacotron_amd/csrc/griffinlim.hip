@@ -61,9 +61,15 @@ __device__ __forceinline__ float gl_ola_norm(const float* __restrict__ frames_u,
 
 // np.exp(1j * np.angle(X)) * mag (audio.py:179-180): unit phase where X == 0
 __device__ __forceinline__ cplx gl_rephase_np(cplx X, float mag) {
-    const float a = sqrtf(X.x * X.x + X.y * X.y);
-    if (!(a > 0.f)) return {mag, 0.f};
-    const float s = mag / a;
+    const float a2 = __builtin_fmaf(X.x, X.x, X.y * X.y);
+    if (!(a2 > 1e-37f)) {                         // |X|^2 underflows: scale up first (exact zero -> unit phase)
+        const cplx Y = {X.x * 0x1p64f, X.y * 0x1p64f};
+        const float b2 = __builtin_fmaf(Y.x, Y.x, Y.y * Y.y);
+        if (!(b2 > 0.f)) return {mag, 0.f};
+        const float t = mag * __builtin_amdgcn_rsqf(b2);
+        return {Y.x * t, Y.y * t};
+    }
+    const float s = mag * __builtin_amdgcn_rsqf(a2);
     return {X.x * s, X.y * s};
 }
 
@@ -76,15 +82,20 @@ __device__ __forceinline__ cplx gl_rephase_np(cplx X, float mag) {
 // np.pad(mode='reflect'), and the first synthesis starts from caller-supplied random phases exp(2 pi i u) (rotated by
 // conj(W^(lp k))) instead of zero phase. first: 0 = iteration, 1 = first synthesis.
 // LDS: [y segment: (run-1)*hop + win floats][window: win floats][twiddle tables: FFT_TW + 512 cplx][4 x FFT_LDS cplx]
-template <bool LIBROSA>
+// WIN_C / HOP_C: compile-time window and hop (the default 1200 / 300) so the range tests, the divisions by the hop and
+// the LDS offsets fold; 0 = take the run-time arguments.
+template <bool LIBROSA, int WIN_C, int HOP_C>
 __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __restrict__ frames_in,
                                                              const float* __restrict__ mag,
                                                              float* __restrict__ frames_out,
                                                              const float2* __restrict__ twiddle,
                                                              const float* __restrict__ window,
-                                                             const float* __restrict__ phase_u, int B, int T, int hop,
-                                                             int win, int nbins, int first, int run, int runs_per_utt) {
+                                                             const float* __restrict__ phase_u, int B, int T,
+                                                             int hop_rt, int win_rt, int nbins, int first, int run,
+                                                             int runs_per_utt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gl_smem[];
+    const int win = WIN_C ? WIN_C : win_rt;
+    const int hop = HOP_C ? HOP_C : hop_rt;
     const int seg_cap = (run - 1) * hop + win;
     float* yseg = reinterpret_cast<float*>(gl_smem);
     float* win_s = yseg + ((seg_cap + 3) & ~3);
@@ -270,21 +281,18 @@ void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, f
     static bool attr_set[64] = {};   // more than the default 64 KB of dynamic LDS: the attribute is per device
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (auto* k : {gl_iter_kernel<false, 0, 0>, gl_iter_kernel<true, 0, 0>, gl_iter_kernel<false, 1200, 300>,
+                        gl_iter_kernel<true, 1200, 300>})
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
         attr_set[dev] = true;
     }
     const dim3 grid((unsigned)(B * runs_per_utt));
-    if (librosa)
-        hipLaunchKernelGGL(gl_iter_kernel<true>, grid, dim3(GL_THREADS), lds, s, frames_in, mag, frames_out,
-                           (const float2*)p.twiddle, p.window, phase_u, B, T, p.hop, p.win, p.nbins, first, run,
-                           runs_per_utt);
-    else
-        hipLaunchKernelGGL(gl_iter_kernel<false>, grid, dim3(GL_THREADS), lds, s, frames_in, mag, frames_out,
-                           (const float2*)p.twiddle, p.window, phase_u, B, T, p.hop, p.win, p.nbins, first, run,
-                           runs_per_utt);
+    const bool dflt = p.win == 1200 && p.hop == 300;
+    auto* kern = librosa ? (dflt ? gl_iter_kernel<true, 1200, 300> : gl_iter_kernel<true, 0, 0>)
+                         : (dflt ? gl_iter_kernel<false, 1200, 300> : gl_iter_kernel<false, 0, 0>);
+    hipLaunchKernelGGL(kern, grid, dim3(GL_THREADS), lds, s, frames_in, mag, frames_out, (const float2*)p.twiddle,
+                       p.window, phase_u, B, T, p.hop, p.win, p.nbins, first, run, runs_per_utt);
     if (tm) tm->end(KK_GL_ITER, s);
 }
 
