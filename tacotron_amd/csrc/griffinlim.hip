@@ -132,22 +132,50 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __r
         }
     } else if (!first) {
         // ---- the samples the run covers: y[hop*m0 + i] = sum of the covering frames of the previous iteration
+        // (ascending frame order, as gl_ola and the oracle add them)
         const int seg = (nfr - 1) * hop + win;
-        for (int i = 2 * tid; i < seg; i += 2 * GL_THREADS) {
-            const int g = hop * m0 + i;
-            const int q = g / hop;
-            const int mhi = min(T - 1, q);
-            const int mlo = max(0, q - (nover - 1));
-            float sx = 0.f, sy = 0.f;
-            for (int m2 = mlo; m2 <= mhi; ++m2) {
-                const int off = g - hop * m2;
-                if (off < win) {
-                    const float2 v = *reinterpret_cast<const float2*>(frames_in + (fb + m2) * win + off);
-                    sx += v.x;
-                    sy += v.y;
+        if constexpr (WIN_C != 0 && HOP_C != 0 && HOP_C % 4 == 0 && WIN_C % HOP_C == 0) {
+            // four samples per lane and step, all covering frames' loads issued together (clamped address, the
+            // out-of-range frames multiplied away): the phase is a pure stream of independent 16-byte loads
+            constexpr int NOVER = WIN_C / HOP_C;
+            const float* fu = frames_in + fb * WIN_C;
+#pragma unroll 2
+            for (int i = 4 * tid; i < seg; i += 4 * GL_THREADS) {
+                const int g = HOP_C * m0 + i;
+                const int q = g / HOP_C;
+                const int r = g - q * HOP_C;
+                float4 part[NOVER];
+#pragma unroll
+                for (int d = 0; d < NOVER; ++d) {
+                    const int m2 = q - (NOVER - 1) + d;               // ascending
+                    const int mc = min(max(m2, 0), T - 1);
+                    part[d] = *reinterpret_cast<const float4*>(fu + (long)mc * WIN_C + r + HOP_C * (NOVER - 1 - d));
+                    if (m2 != mc) part[d] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int d = 0; d < NOVER; ++d) {
+                    acc.x += part[d].x; acc.y += part[d].y; acc.z += part[d].z; acc.w += part[d].w;
+                }
+                *reinterpret_cast<float4*>(yseg + i) = acc;
             }
-            *reinterpret_cast<float2*>(yseg + i) = make_float2(sx, sy);
+        } else {
+            for (int i = 2 * tid; i < seg; i += 2 * GL_THREADS) {
+                const int g = hop * m0 + i;
+                const int q = g / hop;
+                const int mhi = min(T - 1, q);
+                const int mlo = max(0, q - (nover - 1));
+                float sx = 0.f, sy = 0.f;
+                for (int m2 = mlo; m2 <= mhi; ++m2) {
+                    const int off = g - hop * m2;
+                    if (off < win) {
+                        const float2 v = *reinterpret_cast<const float2*>(frames_in + (fb + m2) * win + off);
+                        sx += v.x;
+                        sy += v.y;
+                    }
+                }
+                *reinterpret_cast<float2*>(yseg + i) = make_float2(sx, sy);
+            }
         }
     }
     __syncthreads();
