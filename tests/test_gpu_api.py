@@ -243,3 +243,53 @@ def test_synthesizer_extensions(tmp_path):
         assert os.path.getsize(png) > 1000 and open(png, 'rb').read(4) == b'\x89PNG'
     finally:
         hparams.max_iters, hparams.griffin_lim_iters = old
+
+
+def test_c_abi_error_paths(engine, hp, weights):
+    """Error behaviour at the C boundary (include/taco.h conventions): <0 + a message in taco_last_error, nothing
+    launched, the handle stays usable afterwards."""
+    import ctypes
+    import torch
+    from tacotron_amd import _lib
+    lib, h = engine.lib, engine.handle
+    ids, lens = synth_ids(np.random.default_rng(3), 2, 9)
+    d_ids = torch.from_numpy(ids).cuda()
+    d_lens = torch.from_numpy(lens).cuda()
+    enc = torch.empty(2, 9, 256, device='cuda')
+    ws = torch.empty(int(lib.taco_workspace_bytes(h, 2, 9, 4)), dtype=torch.uint8, device='cuda')
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def err():
+        return _lib.last_error()
+
+    # null pointers, empty batch, workspace too small
+    assert lib.taco_encode(h, None, d_lens.data_ptr(), 2, 9, enc.data_ptr(), ws.data_ptr(), ws.numel(), s) < 0
+    assert 'null' in err()
+    assert lib.taco_encode(h, d_ids.data_ptr(), d_lens.data_ptr(), 0, 9, enc.data_ptr(), ws.data_ptr(), ws.numel(), s) < 0
+    assert 'B=0' in err()
+    assert lib.taco_encode(h, d_ids.data_ptr(), d_lens.data_ptr(), 2, 9, enc.data_ptr(), ws.data_ptr(), 1024, s) < 0
+    assert 'workspace' in err()
+    assert lib.taco_workspace_bytes(h, 0, 9, 4) == 0 and lib.taco_workspace_bytes(None, 2, 9, 4) == 0
+    lin = torch.rand(1, 6, hp.num_freq, device='cuda')
+    wav = torch.empty(1, 5 * 300 + 1200, device='cuda')
+    assert lib.taco_griffin_lim(h, lin.data_ptr(), 1, 6, -1, wav.data_ptr(), ws.data_ptr(), ws.numel(), s) < 0
+    assert 'iters' in err()
+    assert lib.taco_griffin_lim_librosa(h, lin.data_ptr(), None, 1, 4, 1, wav.data_ptr(), ws.data_ptr(), ws.numel(), s) < 0
+    assert 'reflect' in err()
+    assert lib.taco_set_decode_graph(h, 7) < 0
+    # taco_create: a missing variable and a wrong shape are reported by name (Saver.restore's NotFound / shape errors)
+    from tacotron_amd.engine import TacoEngine, TacoError
+    w2 = dict(weights)
+    name = sorted(k for k in w2 if 'attention' in k or 'gru' in k.lower())[0]
+    del w2[name]
+    with pytest.raises((TacoError, KeyError, ValueError)) as ei:
+        TacoEngine(w2, hp)
+    assert name.split('/')[-1] in str(ei.value) or name in str(ei.value)
+    w3 = dict(weights)
+    w3[name] = np.zeros((3, 3), np.float32)
+    with pytest.raises((TacoError, ValueError)) as ei:
+        TacoEngine(w3, hp)
+    assert name in str(ei.value)
+    # the handle still works
+    ref = O.encode(ids, lens, weights, hp)
+    assert rel_l1(_np(engine.encode(ids, lens)), ref) < 1e-3
