@@ -279,11 +279,14 @@ struct Loader {
             std::vector<float> pg((size_t)2 * KG * NT), pc((size_t)2 * KC * NT);
             for (int d = 0; d < 2; ++d) {
                 for (int tid = 0; tid < NT; ++tid) {
-                    const int og = tid >> 1, half = tid & 1, oc = tid >> 2, q = tid & 3;
+                    // lane = (k-slice ks of 16 state values, output group): 4 gate outputs x 16 k, 2 candidate x 16 k
+                    const int ks = tid & 7, grp = tid >> 3;
                     for (int i = 0; i < KG; ++i)
-                        pg[((size_t)d * KG + i) * NT + tid] = gk[d]->data[(size_t)(D + (G / 2) * half + i) * 2 * G + og];
+                        pg[((size_t)d * KG + i) * NT + tid] =
+                            gk[d]->data[(size_t)(D + 16 * ks + (i & 15)) * 2 * G + 4 * grp + (i >> 4)];
                     for (int i = 0; i < KC; ++i)
-                        pc[((size_t)d * KC + i) * NT + tid] = ck[d]->data[(size_t)(D + (G / 4) * q + i) * G + oc];
+                        pc[((size_t)d * KC + i) * NT + tid] =
+                            ck[d]->data[(size_t)(D + 16 * ks + (i & 15)) * G + 2 * grp + (i >> 4)];
                 }
             }
             cb.Pg = upload(pg);

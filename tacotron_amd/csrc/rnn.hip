@@ -3,7 +3,8 @@
 // gate/candidate matmuls are hoisted into one conv_gemm ([B*T,128] @ [128,768] + biases); this
 // kernel runs the recurrence, one 512-thread workgroup per (utterance, direction), with the
 // recurrent weights (128x256 gates + 128x128 candidate = 192 KB) resident in VGPRs for all T
-// steps (96 per thread) and the state in LDS.  Pure latency chain: 2 barriers per step.
+// steps (96 per thread) and the state in LDS.  Pure latency chain: 2 barriers per step; per step a lane reads 16 + 16
+// state values from LDS and meets the other k-slices of its outputs through DPP.
 //
 // TF GRUCell: g = sigmoid([x,h] Wg + bg); r,u = split(g); c = tanh([x, r*h] Wc + bc);
 // h' = u*h + (1-u)*c.  With sequence_length, steps t >= len emit 0 and keep the state; the
@@ -45,8 +46,13 @@ __global__ __launch_bounds__(BIGRU_THREADS) void bigru_scan_kernel(
 #pragma unroll
     for (int i = 0; i < KC; ++i) wc[i] = Pc[((size_t)dir * KC + i) * NT + tid];
 
-    const int og = tid >> 1, half = tid & 1;   // gates: output og (0..255), k in [64*half, +64)
-    const int oc = tid >> 2, q = tid & 3;      // cand : output oc (0..127), k in [32*q, +32)
+    // gates: lane = (k-slice ks of 16, group of 4 outputs); candidate: (k-slice of 16, group of 2 outputs).
+    // A lane reads only its 16 state values (4 ds_read_b128): the LDS return path, not the FMAs, bounds a step when
+    // every lane pulls 64 of them (8 waves x 16 x 1 KB per step); the 8 k-slices of an output meet through three DPP
+    // adds (lane^1, lane^2, half-row mirror), and lanes ks < 4 (ks < 2) finish one output each.
+    const int ks = tid & 7, grp = tid >> 3;
+    const int og = 4 * grp + (ks & 3);         // gate output finished by this lane when ks < 4 (0..255)
+    const int oc = 2 * grp + (ks & 1);         // candidate output finished by this lane when ks < 2 (0..127)
     if (tid < H) { hs[0][tid] = 0.f; hs[1][tid] = 0.f; }
 
     const float* xrow = xp + (size_t)b * T * (6 * H) + dir * 3 * H;
@@ -59,69 +65,89 @@ __global__ __launch_bounds__(BIGRU_THREADS) void bigru_scan_kernel(
     }
 
     auto tpos = [&](int s) { return dir == 0 ? s : len - 1 - s; };
-    float xg = 0.f, xc = 0.f;
-    if (len > 0) {
-        const float* xr = xrow + (size_t)tpos(0) * 6 * H;
-        if (half == 0) xg = xr[og];
-        if (q == 0) xc = xr[2 * H + oc];
+    // The input projections are read once, straight from HBM: a load issued one step ahead is still in flight when
+    // its value is needed (and vmcnt retires in order, behind the output stores), so they are fetched in chunks of
+    // U steps, a whole chunk (>= U steps of arithmetic) before their first use.
+    constexpr int U = 8;
+    float xg_c[U], xc_c[U], xg_n[U], xc_n[U];
+#define BIGRU_LOAD_CHUNK(S0, G, C)                                                  \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                 \
+        const int sl = min((S0) + u, len - 1);    /* clamped: past the end unused */ \
+        const float* xr = xrow + (size_t)tpos(sl) * 6 * H;                          \
+        G[u] = xr[og];                                                              \
+        C[u] = xr[2 * H + oc];                                                      \
     }
+    if (len > 0) { BIGRU_LOAD_CHUNK(0, xg_c, xc_c) }
     __syncthreads();
 
-    int cur = 0;
-    for (int s = 0; s < len; ++s) {
-        // prefetch next step's input projections
-        float xg_n = 0.f, xc_n = 0.f;
-        if (s + 1 < len) {
-            const float* xr = xrow + (size_t)tpos(s + 1) * 6 * H;
-            if (half == 0) xg_n = xr[og];
-            if (q == 0) xc_n = xr[2 * H + oc];
-        }
-        const float* h = hs[cur];
-        // ---- gates
-        {
-            const float4* h4 = reinterpret_cast<const float4*>(h + 64 * half);
-            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};     // packed fp32 FMAs: two MACs per instruction
+    auto sum8 = [](float x) {
+        x += dpp_mov<0xB1>(x);                 // lane ^ 1
+        x += dpp_mov<0x4E>(x);                 // lane ^ 2
+        x += dpp_mov<0x141>(x);                // row_half_mirror: the other quad of the 8
+        return x;
+    };
+
+    for (int s0 = 0; s0 < len; s0 += U) {
+        if (s0 + U < len) { BIGRU_LOAD_CHUNK(s0 + U, xg_n, xc_n) }
 #pragma unroll
-            for (int i = 0; i < KG / 4; ++i) {
-                const float4 hv = h4[i];
-                a01 = __builtin_elementwise_fma(f32x2{wg[4 * i + 0], wg[4 * i + 1]}, f32x2{hv.x, hv.y}, a01);
-                a23 = __builtin_elementwise_fma(f32x2{wg[4 * i + 2], wg[4 * i + 3]}, f32x2{hv.z, hv.w}, a23);
-            }
-            float acc = (a01.x + a01.y) + (a23.x + a23.y);
-            acc += dpp_mov<0xB1>(acc);             // lane ^ 1 (DPP quad_perm, no LDS round trip)
-            if (half == 0) {
-                const float g = sigmoidf_(acc + xg);
-                if (og < H) rh[og] = g * h[og];
-                else us[og - H] = g;
-            }
-        }
-        __syncthreads();
-        // ---- candidate + state update
-        {
-            const float4* r4 = reinterpret_cast<const float4*>(rh + 32 * q);
-            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+        for (int u = 0; u < U; ++u) {
+            const int s = s0 + u;
+            if (s >= len) break;
+            const int cur = s & 1;
+            const float* h = hs[cur];
+            // ---- gates
+            {
+                const float4* h4 = reinterpret_cast<const float4*>(h + 16 * ks);
+                const float h_own = h[og & (H - 1)];       // for r*h: read up front, not behind the sigmoid
+                const float4 v0 = h4[0], v1 = h4[1], v2 = h4[2], v3 = h4[3];
+                const f32x2 hp[8] = {{v0.x, v0.y}, {v0.z, v0.w}, {v1.x, v1.y}, {v1.z, v1.w},
+                                     {v2.x, v2.y}, {v2.z, v2.w}, {v3.x, v3.y}, {v3.z, v3.w}};
+                float sj[4];
 #pragma unroll
-            for (int i = 0; i < KC / 4; ++i) {
-                const float4 rv = r4[i];
-                a01 = __builtin_elementwise_fma(f32x2{wc[4 * i + 0], wc[4 * i + 1]}, f32x2{rv.x, rv.y}, a01);
-                a23 = __builtin_elementwise_fma(f32x2{wc[4 * i + 2], wc[4 * i + 3]}, f32x2{rv.z, rv.w}, a23);
+                for (int j = 0; j < 4; ++j) {
+                    f32x2 a = {0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        a = __builtin_elementwise_fma(f32x2{wg[16 * j + 2 * i], wg[16 * j + 2 * i + 1]}, hp[i], a);
+                    sj[j] = sum8(a.x + a.y);
+                }
+                if (ks < 4) {
+                    const float acc = (ks & 2) ? ((ks & 1) ? sj[3] : sj[2]) : ((ks & 1) ? sj[1] : sj[0]);
+                    const float g = sigmoidf_(acc + xg_c[u]);
+                    if (og < H) rh[og] = g * h_own;
+                    else us[og - H] = g;
+                }
             }
-            float acc = (a01.x + a01.y) + (a23.x + a23.y);
-            acc += dpp_mov<0xB1>(acc);             // lane ^ 1
-            acc += dpp_mov<0x4E>(acc);             // lane ^ 2
-            if (q == 0) {
-                const float c = tanhf_(acc + xc);
-                const float u = us[oc];
-                const float hn = u * h[oc] + (1.f - u) * c;
-                hs[cur ^ 1][oc] = hn;
-                orow[(size_t)tpos(s) * 2 * H + oc] = hn;
+            __syncthreads();
+            // ---- candidate + state update
+            {
+                const float4* r4 = reinterpret_cast<const float4*>(rh + 16 * ks);
+                const float uu = us[oc], h_own = h[oc];
+                const float4 v0 = r4[0], v1 = r4[1], v2 = r4[2], v3 = r4[3];
+                const f32x2 rp[8] = {{v0.x, v0.y}, {v0.z, v0.w}, {v1.x, v1.y}, {v1.z, v1.w},
+                                     {v2.x, v2.y}, {v2.z, v2.w}, {v3.x, v3.y}, {v3.z, v3.w}};
+                float sj[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x2 a = {0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        a = __builtin_elementwise_fma(f32x2{wc[16 * j + 2 * i], wc[16 * j + 2 * i + 1]}, rp[i], a);
+                    sj[j] = sum8(a.x + a.y);
+                }
+                if (ks < 2) {
+                    const float c = tanhf_((ks & 1 ? sj[1] : sj[0]) + xc_c[u]);
+                    const float hn = uu * h_own + (1.f - uu) * c;
+                    hs[cur ^ 1][oc] = hn;
+                    orow[(size_t)tpos(s) * 2 * H + oc] = hn;
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
-        cur ^= 1;
-        xg = xg_n;
-        xc = xc_n;
+#pragma unroll
+        for (int u = 0; u < U; ++u) { xg_c[u] = xg_n[u]; xc_c[u] = xc_n[u]; }
     }
+#undef BIGRU_LOAD_CHUNK
 }
 
 void launch_bigru_scan(const float* xp, const float* Pg, const float* Pc, const int32_t* lens, float* out,
