@@ -73,7 +73,11 @@ __device__ __forceinline__ f32x4 gq_val(const GQuad& g) {
     const unsigned a = g.lo.x, b = g.lo.z, c = g.hi.x, d = g.hi.z;
     return f32x4{__uint_as_float(a), __uint_as_float(b), __uint_as_float(c), __uint_as_float(d)};
 }
-__device__ __forceinline__ void pd_stg(__amdgpu_buffer_rsrc_t rs, unsigned float_off, f32x4 v, unsigned tag) {
+// (`on` = this lane's batch column is a real utterance: the columns that pad the last tile are neither published nor
+// polled, so a small batch moves proportionally fewer granules per hand-off)
+__device__ __forceinline__ void pd_stg(__amdgpu_buffer_rsrc_t rs, unsigned float_off, f32x4 v, unsigned tag,
+                                       bool on = true) {
+    if (!on) return;
     const float a = v.x, b = v.y, c = v.z, d = v.w;
     const u32x4 lo = {__float_as_uint(a), tag, __float_as_uint(b), tag};
     const u32x4 hi = {__float_as_uint(c), tag, __float_as_uint(d), tag};
@@ -130,7 +134,7 @@ struct Segs { unsigned off0, tag0; int e0; unsigned off1, tag1; int e1; unsigned
 template <int CH, int NX, int E0 = PD_BATCH>   // E0: size of the first batch (so that later batches line up with a segment)
 __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_rsrc_t rs, const Segs sg, int nk16,
                                         int Bpad, int lb, int lq, int wave_v, int lane, f32x4* red, Spin& spin,
-                                        Extra* ex) {
+                                        Extra* ex, bool col_on) {
     const int wave = __builtin_amdgcn_readfirstlane(wave_v);              // provably uniform -> scalar addressing
     const unsigned lane_bytes = (unsigned)(lq * Bpad + lb) * 32u;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -143,8 +147,8 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
         if (h >= CH) break;
         const bool last = h + hn >= CH;      // the epilogue operands (update gate, residual) ride with the last batch:
                                              // a late one must not hold back K segments that are already there
-        GQuad g[PD_BATCH];
-        GQuad gx[NX > 0 ? NX : 1];
+        GQuad g[PD_BATCH] = {};              // (padding columns stay zero: never loaded, never waited for)
+        GQuad gx[NX > 0 ? NX : 1] = {};
         // a k16-step that has arrived is not fetched again: a retry only re-reads what is still missing
         bool have[PD_BATCH], havex[NX > 0 ? NX : 1];
 #pragma unroll
@@ -161,13 +165,13 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
                     const unsigned off = s == 0 ? sg.off0 : (s == 1 ? sg.off1 : sg.off2);
                     const int kb = s == 0 ? 0 : (s == 1 ? sg.e0 : sg.e1);
                     const unsigned uni = (off + (unsigned)(4 * (ks - kb) * Bpad) * 8u) * 4u;
-                    g[i] = pd_ldg2(rs, lane_bytes, uni);
+                    if (col_on) g[i] = pd_ldg2(rs, lane_bytes, uni);
                 }
             }
             if (NX > 0 && last && wave == 0) {
 #pragma unroll
                 for (int i = 0; i < NX; ++i)
-                    if (!havex[i]) gx[i] = pd_ldg(rs, ex[i].off);
+                    if (!havex[i] && col_on) gx[i] = pd_ldg(rs, ex[i].off);
             }
 #pragma unroll
             for (int i = 0; i < PD_BATCH; ++i) {
@@ -175,7 +179,7 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
                 if (i < hn && h + i < CH && ks < nk16 && !have[i]) {
                     const int s = ks < sg.e0 ? 0 : (ks < sg.e1 ? 1 : 2);
                     const unsigned tag = s == 0 ? sg.tag0 : (s == 1 ? sg.tag1 : sg.tag2);
-                    have[i] = __all(gq_ok(g[i], tag));
+                    have[i] = __all(!col_on || gq_ok(g[i], tag));
                     ok = ok && have[i];
                 }
             }
@@ -183,7 +187,7 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
 #pragma unroll
                 for (int i = 0; i < NX; ++i)
                     if (!havex[i]) {
-                        havex[i] = __all(gq_ok(gx[i], ex[i].tag));
+                        havex[i] = __all(!col_on || gq_ok(gx[i], ex[i].tag));
                         ok = ok && havex[i];
                     }
             }
@@ -284,6 +288,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
     const int bt = blockIdx.x >> 5, j = blockIdx.x & 31;
     const int b0 = bt * 16, Bpad = a.Bpad;
     const int lb = b0 + (lane & 15), lq = lane >> 4;
+    const bool col_on = lb < a.B;            // this lane's batch column is a real utterance
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.region, 0, a.region_bytes, 0x00020000);
     Spin spin{reinterpret_cast<unsigned*>(a.sync) + 1, 0u, false, 0u, 0ull};
 #ifdef PD_STAMPS
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
 #define PD_STAMP() do {} while (0)
 #endif
 #define PD_BIAS(sl) (*reinterpret_cast<const f32x4*>(bias_s + (sl) * 16 + 4 * lq))
-#define PD_MMA(CH, NX, W, SG, nk, EX) pd_mma<CH, NX>(W, rs, SG, nk, Bpad, lb, lq, wave, lane, red, spin, EX)
+#define PD_MMA(CH, NX, W, SG, nk, EX) pd_mma<CH, NX>(W, rs, SG, nk, Bpad, lb, lq, wave, lane, red, spin, EX, col_on)
     // the r output frames of step `so` (decoder.py:35) from o2, which must carry tag `to2`
 #define PD_OUT(so, to2)                                                                                              \
     do {                                                                                                             \
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
             f32x4 v = PD_MMA(4, 0, o4, sgo, 16, ex);                                                                 \
             if (wave == 0)                                                                                           \
                 pd_stg(rs, a.o_outQ + (unsigned)((so) * 400) * Bpad * 2u + (roleA ? te16 : te), v + PD_BIAS(SL_O4),  \
-                       (to2) + 1u);                                                                                  \
+                       (to2) + 1u, col_on);                                                                          \
         }                                                                                                            \
     } while (0)
 
@@ -416,13 +421,13 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
         if (roleA) {
             const Segs sg{o_ctxp, s ? Tp + 7u : 0u, 16, a.o_o2, s ? Tp + 12u : 0u, 32, 0u, 0u};
             f32x4 v = PD_MMA(8, 0, x8a, sg, 32, ex);
-            if (wave == 0) pd_stg(rs, a.o_p1 + te, relu4(v + PD_BIAS(s ? SL_X8A : SL_GO)), T + 1u);
+            if (wave == 0) pd_stg(rs, a.o_p1 + te, relu4(v + PD_BIAS(s ? SL_X8A : SL_GO)), T + 1u, col_on);
         }
         if (s) PD_OUT(s - 1, Tp + 12u);       // previous step's frames: off the dependency chain
         if (!roleA && k < 8) {
             const Segs sg{a.o_p1, T + 1u, 16, 0u, 0u, 16, 0u, 0u};
             f32x4 v = PD_MMA(4, 0, pd_sub<4>(x12, 6), sg, 16, ex);
-            if (wave == 0) pd_stg(rs, a.o_p2 + te, relu4(v + PD_BIAS(SL_X8B1)), T + 2u);
+            if (wave == 0) pd_stg(rs, a.o_p2 + te, relu4(v + PD_BIAS(SL_X8B1)), T + 2u, col_on);
         }
         PD_STAMP();
         // ---- stage 2/3: attention GRU (rnn_wrappers.py:26): gates (A: update tile, B: reset tile), candidate (B)
@@ -431,20 +436,20 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
             f32x4 v = PD_MMA(6, 0, a6, sg, 24, ex);
             if (wave == 0) {
                 const f32x4 g = sig4(v + PD_BIAS(SL_A6));
-                if (roleA) pd_stg(rs, a.o_u + te, g, T + 3u);
-                else pd_stg(rs, a.o_rh + te, g * hA_t, T + 3u);
+                if (roleA) pd_stg(rs, a.o_u + te, g, T + 3u, col_on);
+                else pd_stg(rs, a.o_rh + te, g * hA_t, T + 3u, col_on);
             }
         }
         PD_STAMP();
         if (!roleA) {
             ex[0].off = a.o_u + te; ex[0].tag = T + 3u;
             const Segs sg{a.o_p2, T + 2u, 8, a.o_rh, T + 3u, 24, 0u, 0u};
-            f32x4 v = pd_mma<6, 1, 2>(pd_sub<6>(x12, 0), rs, sg, 24, Bpad, lb, lq, wave, lane, red, spin, ex);
+            f32x4 v = pd_mma<6, 1, 2>(pd_sub<6>(x12, 0), rs, sg, 24, Bpad, lb, lq, wave, lane, red, spin, ex, col_on);
             if (wave == 0) {
                 const f32x4 ug = ex[0].val;
                 const f32x4 c = tanh4(v + PD_BIAS(SL_X12));
                 hA_t = ug * hA_t + (1.f - ug) * c;
-                pd_stg(rs, hc + te, hA_t, T + 4u);
+                pd_stg(rs, hc + te, hA_t, T + 4u, col_on);
             }
         }
         PD_STAMP();
@@ -452,17 +457,11 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
             // ---- stage 4: attention query (decoder.py:20)
             const Segs sq{hc, T + 4u, 16, 0u, 0u, 16, 0u, 0u};
             f32x4 v = PD_MMA(4, 0, pd_sub<4>(x8b, 0), sq, 16, ex);
-            if (wave == 0) pd_stg(rs, a.o_q + te, v, T + 5u);
+            if (wave == 0) pd_stg(rs, a.o_q + te, v, T + 5u, col_on);
         }
         PD_STAMP();
         // ---- stage 5/6: Bahdanau scores, softmax, context (all workgroups)
-        if (!att_on) {
-            // padded column of the last 16-utterance tile: no attention, but its context quads must still carry this
-            // step's tag for the stages that read whole tiles (ordered after q, like the real ones)
-            (void)pd_wait_quad(rs, a.o_q + (unsigned)(lane * Bpad + b_att) * 8u, T + 5u, spin);
-            if (tid < 32)
-                pd_stg(rs, o_ctx + (unsigned)((hf * 32 + tid) * Bpad + b_att) * 8u, f32x4{0.f, 0.f, 0.f, 0.f}, T + 7u);
-        }
+        // (workgroups whose attention utterance is a padding column skip the stage: nobody reads that column)
         if (att_on) {
             // scores of this half: e_t = sum_d v_d tanh(keys[t,d] + q_d); lane owns dims 4*lane..+3, wave owns t
             const f32x4 qq = pd_wait_quad(rs, a.o_q + (unsigned)(lane * Bpad + b_att) * 8u, T + 5u, spin);
@@ -608,8 +607,8 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
             f32x4 v = PD_MMA(12, 0, g12, sg, 48, ex);
             if (wave == 0) {
                 const f32x4 g = sig4(v + PD_BIAS(SL_G12));
-                if (roleA) pd_stg(rs, a.o_rh + st_stride + te, g * hA_t, T + 9u);
-                else pd_stg(rs, a.o_u + st_stride + te, g, T + 9u);
+                if (roleA) pd_stg(rs, a.o_rh + st_stride + te, g * hA_t, T + 9u, col_on);
+                else pd_stg(rs, a.o_u + st_stride + te, g, T + 9u, col_on);
             }
         }
         PD_STAMP();
@@ -618,7 +617,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
             // role A is busy with the candidate, which picks its tile up with its update gate
             const Segs sp{hc, T + 4u, 16, o_ctx, T + 7u, 32, 0u, 0u};
             f32x4 v = PD_MMA(8, 0, x8b, sp, 32, ex);
-            if (wave == 0) pd_stg(rs, a.o_d0 + te, v + PD_BIAS(SL_X8B0), T + 8u);
+            if (wave == 0) pd_stg(rs, a.o_d0 + te, v + PD_BIAS(SL_X8B0), T + 8u, col_on);
         } else {
             ex[0].off = a.o_u + st_stride + te; ex[0].tag = T + 9u;
             ex[1].off = a.o_d0 + te; ex[1].tag = T + 8u;
@@ -629,8 +628,8 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
                 const f32x4 c = tanh4(v + PD_BIAS(SL_X12));
                 hA_t = ug * hA_t + (1.f - ug) * c;
                 o1_t = hA_t + ex[1].val;
-                pd_stg(rs, a.o_h1 + cur + te, hA_t, T + 10u);
-                pd_stg(rs, a.o_o1 + te, o1_t, T + 10u);
+                pd_stg(rs, a.o_h1 + cur + te, hA_t, T + 10u, col_on);
+                pd_stg(rs, a.o_o1 + te, o1_t, T + 10u, col_on);
             }
         }
         PD_STAMP();
@@ -640,8 +639,8 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
             f32x4 v = PD_MMA(8, 0, g8, sg, 32, ex);
             if (wave == 0) {
                 const f32x4 g = sig4(v + PD_BIAS(SL_G8));
-                if (roleA) pd_stg(rs, a.o_u + 2u * st_stride + te, g, T + 11u);
-                else pd_stg(rs, a.o_rh + 2u * st_stride + te, g * hB_t, T + 11u);
+                if (roleA) pd_stg(rs, a.o_u + 2u * st_stride + te, g, T + 11u, col_on);
+                else pd_stg(rs, a.o_rh + 2u * st_stride + te, g * hB_t, T + 11u, col_on);
             }
         }
         PD_STAMP();
@@ -654,8 +653,8 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
                 const f32x4 ug = ex[0].val;
                 const f32x4 c = tanh4(v + PD_BIAS(SL_X8A));
                 hB_t = ug * hB_t + (1.f - ug) * c;
-                pd_stg(rs, a.o_h2 + cur + te, hB_t, T + 12u);
-                pd_stg(rs, a.o_o2 + te, hB_t + ex[1].val, T + 12u);
+                pd_stg(rs, a.o_h2 + cur + te, hB_t, T + 12u, col_on);
+                pd_stg(rs, a.o_o2 + te, hB_t + ex[1].val, T + 12u, col_on);
             }
         }
         PD_STAMP();
