@@ -303,6 +303,9 @@ void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, f
     // frames per workgroup: as many as keep the y segment within ~24 KB of LDS (2 workgroups per CU and more)
     int run = GL_RUN;
     while (run > 1 && ((size_t)(run - 1) * p.hop + p.win) * 4 > 24 * 1024) --run;
+    // small jobs: shorter runs (down to one frame per wave) until the grid covers the chip twice; the overlap-add
+    // order per sample does not depend on the run length, so results are bit-identical
+    while (run > GL_WAVES && (long)B * ((T + run - 1) / run) < 512) run -= GL_WAVES;
     const int runs_per_utt = (T + run - 1) / run;
     const size_t lds = (size_t)((((run - 1) * p.hop + p.win + 3) & ~3) + ((p.win + 3) & ~3)) * 4 +
                        (size_t)(FFT_TW + FFT_N / 2 + GL_WAVES * FFT_LDS) * sizeof(cplx);

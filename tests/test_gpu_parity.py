@@ -388,3 +388,16 @@ def test_spectrogram_analysis(engine, hp, n):
     from tacotron_amd.tools import audio
     assert audio.spectrogram(y, engine).shape == (1025, 1 + n // 300)
     assert audio.mel_spectrogram(y, engine).shape == (80, 1 + n // 300)
+
+
+def test_griffin_lim_batch_and_run_invariance(engine, hp):
+    """An utterance's waveform is bit-identical alone (short runs of frames per workgroup) and inside a large batch
+    (16-frame runs): the overlap-add order per sample does not depend on the launch geometry."""
+    rng = np.random.default_rng(9)
+    lin = rng.uniform(0.3, 1.0, size=(40, 200, 1025)).astype(np.float32)
+    full = _np(engine.griffin_lim(lin, iters=3))
+    for b in (0, 17, 39):
+        assert np.array_equal(_np(engine.griffin_lim(lin[b:b + 1], iters=3))[0], full[b])
+    u = rng.random((40, 200, 1025)).astype(np.float32)
+    full = _np(engine.griffin_lim_librosa(lin, u, iters=2))
+    assert np.array_equal(_np(engine.griffin_lim_librosa(lin[5:6], u[5:6], iters=2))[0], full[5])
