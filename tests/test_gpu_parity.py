@@ -401,3 +401,24 @@ def test_griffin_lim_batch_and_run_invariance(engine, hp):
     u = rng.random((40, 200, 1025)).astype(np.float32)
     full = _np(engine.griffin_lim_librosa(lin, u, iters=2))
     assert np.array_equal(_np(engine.griffin_lim_librosa(lin[5:6], u[5:6], iters=2))[0], full[5])
+
+
+def test_hip_path_matches_committed_goldens():
+    """The HIP path against tests/golden/oracle_small.npz read from disk (no oracle call at run time): the same vectors
+    the CPU suite pins the oracle with (tests/test_cpu_oracle.py::test_oracle_matches_golden_vectors)."""
+    import os
+    from tests.golden.make_oracle_goldens import case
+    from tacotron_amd.engine import TacoEngine
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'oracle_small.npz'))
+    hp, w, ids, lens = case()
+    eng = TacoEngine(w, hp)
+    try:
+        o = eng.finish(eng.synthesize(g['ids'], g['lens'], max_iters=3))
+        assert rel_l1(_np(o['enc_out']), g['enc_out']) < 1e-3
+        assert rel_l1(_np(o['mel']), g['mel']) < 1e-3
+        assert rel_l1(_np(o['linear'])[:, :, ::16], g['linear']) < 1e-3
+        assert rel_l1(_np(o['alignments']), g['alignments']) < 1e-3
+        wav = _np(eng.griffin_lim(g['gl_linear'], iters=2))
+        assert np.linalg.norm(wav - g['gl_wav']) / np.linalg.norm(g['gl_wav']) < 1e-4
+    finally:
+        eng.close()
