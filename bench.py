@@ -131,7 +131,7 @@ def cpu_baseline(hp, weights, T_in, S, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
     ap.add_argument('--t-in', type=int, default=150)
