@@ -266,6 +266,12 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
 }
 
+// workgroups per utterance for the attention of a tile that holds n (1..16) utterances: 32 / (n rounded up to a power
+// of two), at least 2
+__host__ __device__ inline int pd_att_parts(int n) {
+    return n <= 1 ? 32 : (n <= 2 ? 16 : (n <= 4 ? 8 : (n <= 8 ? 4 : 2)));
+}
+
 template <int N, int CH>
 __device__ __forceinline__ float4 (&pd_sub(float4 (&w)[CH], int first))[N] {
     return *reinterpret_cast<float4(*)[N]>(&w[first]);
@@ -280,9 +286,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
     const int T4 = (a.T_in + 3) & ~3;
     float* p_s = e_s + T4;                                               // [T_in rounded to 4] exp(score - max)
     float* wsum_s = p_s + T4;                                            // [4] per-wave partial sums, [4..7] key range flags
-    float* keys_s = wsum_s + 8;                                          // [Th][256] when staged
-    const int Th = (a.T_in + 1) >> 1;
-    float* vals_s = keys_s + (a.lds_keys ? Th * 256 : 0);                // [T_in][128] when staged
+    float* keys_s = wsum_s + 8;                                          // [Tp][256] when staged
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bt = blockIdx.x >> 5, j = blockIdx.x & 31;
@@ -343,13 +347,21 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
         }
         bias_s[i] = (bp && tile < nt) ? bp[tile * 16 + r] : 0.f;
     }
-    // ---- attention role: utterance u of the group, half `hf` (keys: half of T_in; values: half of the channels)
-    const int u_loc = j >> 1, hf = j & 1;
+    // ---- attention role: the 32 workgroups of a tile share its utterances' attention, P = 2 .. 32 workgroups per
+    // utterance (2 for a full tile of 16, all 32 for a single utterance): part `part` of utterance u scores the key
+    // rows [part Tp, (part+1) Tp) and builds 256/P channels of the context. What a workgroup stages in LDS shrinks
+    // with P, so a small batch keeps long inputs' keys and values on chip too. The arithmetic per score row and per
+    // context channel does not depend on P (see the context loop), so an utterance's result does not either.
+    const int P = pd_att_parts(min(16, a.B - b0));
+    const int u_loc = j / P, part = j - u_loc * P;
     const int b_att = b0 + u_loc;
     const bool att_on = b_att < a.B;
-    const int t_lo = hf ? Th : 0, t_n = hf ? a.T_in - Th : Th;           // this half's score range
+    const int Tp = (a.T_in + P - 1) / P;
+    const int t_lo = min(part * Tp, a.T_in), t_n = min(Tp, a.T_in - t_lo);   // this part's score rows
+    const int nq = 64 / P;                                                   // context channel quads of this part
+    float* vals_s = keys_s + (a.lds_keys ? Tp * 256 : 0);                    // [T_in][nq] float4 when staged
     const float* keys_g = a.keys + ((size_t)(att_on ? b_att : 0) * a.T_in + t_lo) * 256;
-    const float* vals_g = a.values + (size_t)(att_on ? b_att : 0) * a.T_in * 256 + hf * 128;
+    const float* vals_g = a.values + (size_t)(att_on ? b_att : 0) * a.T_in * 256 + part * nq * 4;
     // Fast score path: tanh(k + q) = 1 - 2 / (E_k E_q + 1) with E_x = 2^(2 log2(e) x). E_k is stored instead of k when
     // every |k| of this half is below 40 (E_k finite and normal; a product that overflows or underflows still gives the
     // right +-1). A step whose |q| reaches 40 reads the plain keys from global memory instead.
@@ -376,9 +388,9 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
             }
         }
         if (a.lds_vals)
-            for (int i = tid; i < a.T_in * 32; i += PD_THREADS)
+            for (int i = tid; i < a.T_in * nq; i += PD_THREADS)
                 reinterpret_cast<float4*>(vals_s)[i] =
-                    reinterpret_cast<const float4*>(vals_g + (size_t)(i >> 5) * 256)[i & 31];
+                    reinterpret_cast<const float4*>(vals_g + (size_t)(i / nq) * 256)[i % nq];
     }
     const float4 v_att = reinterpret_cast<const float4*>(a.attn_v)[lane];
     __syncthreads();
@@ -491,8 +503,9 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
                                   __builtin_amdgcn_exp2f(qq.z * c2), __builtin_amdgcn_exp2f(qq.w * c2)};
                 const float sv = (v_att.x + v_att.y) + (v_att.z + v_att.w);
                 const float4* kp = reinterpret_cast<const float4*>(keys_s);
-                float4 k0 = kp[wave * 64 + lane];
-                float4 k1 = kp[(wave + PD_WAVES < t_n ? wave + PD_WAVES : wave) * 64 + lane];
+                const int tw0 = wave < t_n ? wave : 0;                 // (a part may have fewer rows than waves)
+                float4 k0 = kp[tw0 * 64 + lane];
+                float4 k1 = kp[(wave + PD_WAVES < t_n ? wave + PD_WAVES : tw0) * 64 + lane];
                 for (int t = wave; t < t_n; t += 2 * PD_WAVES) {
                     const int t1 = t + PD_WAVES, tn = t + 2 * PD_WAVES, tn1 = tn + PD_WAVES;
                     // next pair's keys in flight under this pair's arithmetic
@@ -531,17 +544,18 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
                                                       (a.o_e + (unsigned)(b_att * a.T_in + t_lo + t) * 2u) * 4u, 0, 16);
             PD_STAMP();
             {
-                const int o_lo = hf ? 0 : Th, o_n = a.T_in - t_n;
+                const int o_n = a.T_in - t_n;                      // the rows of the other parts: [0, t_lo), [t_lo + t_n, T_in)
                 for (int t0 = 0; t0 < o_n; t0 += PD_THREADS) {
-                    const int t = t0 + tid;
+                    const int ti = t0 + tid;
+                    const int t = ti < t_lo ? ti : ti + t_n;
                     u32x2 g = {0u, T + 6u};
                     spin.begin(T + 6u);
                     while (true) {
-                        if (t < o_n)
-                            g = __builtin_amdgcn_raw_buffer_load_b64(rs, (a.o_e + (unsigned)(b_att * a.T_in + o_lo + t) * 2u) * 4u, 0, 16);
+                        if (ti < o_n)
+                            g = __builtin_amdgcn_raw_buffer_load_b64(rs, (a.o_e + (unsigned)(b_att * a.T_in + t) * 2u) * 4u, 0, 16);
                         if (__all(g.y == T + 6u) || spin.give_up()) break;
                     }
-                    if (t < o_n) e_s[o_lo + t] = __uint_as_float(g.x);
+                    if (ti < o_n) e_s[t] = __uint_as_float(g.x);
                 }
             }
             __syncthreads();
@@ -566,35 +580,40 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
                 inv = 1.f / ((wsum_s[0] + wsum_s[1]) + (wsum_s[2] + wsum_s[3]));
             }
             PD_STAMP();
-            // context, this half's 128 channels: lane = (t parity, channel quad), waves stride t by 8
-            const int dq = lane & 31, tp = lane >> 5;
+            // context, this part's nq channel quads: thread = (class c of t mod 8, quad); a channel is always the sum of
+            // the same eight partial sums over t = c, c + 8, ..., combined in the same order, whatever P is (for P = 2
+            // this is lane = (t parity, quad), waves striding t by 8)
+            const int dq = tid % nq, tc = tid / nq;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (a.lds_vals) {
-                const float4* vp = reinterpret_cast<const float4*>(vals_s);
+            if (tc < 8) {
+                if (a.lds_vals) {
+                    const float4* vp = reinterpret_cast<const float4*>(vals_s);
 #pragma unroll 5
-                for (int t = 2 * wave + tp; t < a.T_in; t += 2 * PD_WAVES) {
-                    const float4 x = vp[t * 32 + dq];
-                    const float p = p_s[t];
-                    acc.x = fmaf(p, x.x, acc.x); acc.y = fmaf(p, x.y, acc.y);
-                    acc.z = fmaf(p, x.z, acc.z); acc.w = fmaf(p, x.w, acc.w);
+                    for (int t = tc; t < a.T_in; t += 8) {
+                        const float4 x = vp[t * nq + dq];
+                        const float p = p_s[t];
+                        acc.x = fmaf(p, x.x, acc.x); acc.y = fmaf(p, x.y, acc.y);
+                        acc.z = fmaf(p, x.z, acc.z); acc.w = fmaf(p, x.w, acc.w);
+                    }
+                } else {
+#pragma unroll 5
+                    for (int t = tc; t < a.T_in; t += 8) {
+                        const float4 x = reinterpret_cast<const float4*>(vals_g + (size_t)t * 256)[dq];
+                        const float p = p_s[t];
+                        acc.x = fmaf(p, x.x, acc.x); acc.y = fmaf(p, x.y, acc.y);
+                        acc.z = fmaf(p, x.z, acc.z); acc.w = fmaf(p, x.w, acc.w);
+                    }
                 }
-            } else {
-                for (int t = 2 * wave + tp; t < a.T_in; t += 2 * PD_WAVES) {
-                    const float4 x = reinterpret_cast<const float4*>(vals_g + (size_t)t * 256)[dq];
-                    const float p = p_s[t];
-                    acc.x = fmaf(p, x.x, acc.x); acc.y = fmaf(p, x.y, acc.y);
-                    acc.z = fmaf(p, x.z, acc.z); acc.w = fmaf(p, x.w, acc.w);
-                }
+                red[tid] = acc;                    // [class][quad]
             }
-            red[wave * 64 + lane] = acc;
             __syncthreads();
-            if (tid < 32) {
-                f32x4 c = red[tid] + red[32 + tid];
+            if (tid < nq) {
+                f32x4 c = red[tid] + red[nq + tid];
 #pragma unroll
-                for (int ww = 1; ww < PD_WAVES; ++ww) c += red[ww * 64 + tid] + red[ww * 64 + 32 + tid];
-                pd_stg(rs, o_ctx + (unsigned)((hf * 32 + tid) * Bpad + b_att) * 8u, c * inv, T + 7u);
+                for (int ww = 1; ww < 4; ++ww) c += red[(2 * ww) * nq + tid] + red[(2 * ww + 1) * nq + tid];
+                pd_stg(rs, o_ctx + (unsigned)((part * nq + tid) * Bpad + b_att) * 8u, c * inv, T + 7u);
             }
-            if (hf == 0) {      // alignment row (tacotron.py:51 gets it transposed at the end): off the chain
+            if (part == 0) {    // alignment row (tacotron.py:51 gets it transposed at the end): off the chain
                 float* arow = a.alignS + ((size_t)s * a.B + b_att) * a.T_in;
                 for (int t = tid; t < a.T_in; t += PD_THREADS) arow[t] = p_s[t] * inv;
             }
@@ -673,12 +692,14 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
 #undef PD_BIAS
 }
 
-size_t dec_persistent_lds_bytes(int T_in, int* lds_keys, int* lds_vals) {
+// LDS of a launch: sized for its fullest tile (the first one), whose workgroups hold the largest parts
+size_t dec_persistent_lds_bytes(int T_in, int B, int* lds_keys, int* lds_vals) {
     const size_t cap = 160 * 1024;
-    const int T4 = (T_in + 3) & ~3, Th = (T_in + 1) >> 1;
+    const int P = pd_att_parts(B < 16 ? B : 16);
+    const int T4 = (T_in + 3) & ~3, Tp = (T_in + P - 1) / P;
     size_t base = 8192 + (size_t)ST_COUNT * 16 * 4 + (size_t)T4 * 8 + 32;
     base = (base + 15) & ~(size_t)15;
-    const size_t kb = (size_t)Th * 1024, vb = (size_t)T_in * 512;
+    const size_t kb = (size_t)Tp * 1024, vb = (size_t)T_in * (256 / P) * 4;
     *lds_keys = base + kb <= cap;
     *lds_vals = base + (*lds_keys ? kb : 0) + vb <= cap;
     return base + (*lds_keys ? kb : 0) + (*lds_vals ? vb : 0);
@@ -695,7 +716,7 @@ int launch_dec_persistent(DecPersistArgs a, hipStream_t s, Timing* tm) {
             return -1;
         attr_set[dev] = true;
     }
-    const size_t lds = dec_persistent_lds_bytes(a.T_in, &a.lds_keys, &a.lds_vals);
+    const size_t lds = dec_persistent_lds_bytes(a.T_in, a.B, &a.lds_keys, &a.lds_vals);
     if (tm) tm->begin(KK_DEC_PERSIST, s);
     hipLaunchKernelGGL(dec_persistent_kernel, dim3(32 * (a.Bpad / 16)), dim3(PD_THREADS), lds, s, a);
     if (tm) tm->end(KK_DEC_PERSIST, s);
