@@ -359,18 +359,22 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
     const int Tp = (a.T_in + P - 1) / P;
     const int t_lo = min(part * Tp, a.T_in), t_n = min(Tp, a.T_in - t_lo);   // this part's score rows
     const int nq = 64 / P;                                                   // context channel quads of this part
-    float* vals_s = keys_s + (a.lds_keys ? Tp * 256 : 0);                    // [T_in][nq] float4 when staged
+    const int kl = min(t_n, a.lds_keys);                                     // key rows of this part held in LDS
+    float* vals_s = keys_s + min(Tp, a.lds_keys) * 256;                      // [T_in][nq] float4 when staged
     const float* keys_g = a.keys + ((size_t)(att_on ? b_att : 0) * a.T_in + t_lo) * 256;
     const float* vals_g = a.values + (size_t)(att_on ? b_att : 0) * a.T_in * 256 + part * nq * 4;
     // Fast score path: tanh(k + q) = 1 - 2 / (E_k E_q + 1) with E_x = 2^(2 log2(e) x). E_k is stored instead of k when
-    // every |k| of this half is below 40 (E_k finite and normal; a product that overflows or underflows still gives the
-    // right +-1). A step whose |q| reaches 40 reads the plain keys from global memory instead.
+    // every |k| of the UTTERANCE is below 40 (E_k finite and normal; a product that overflows or underflows still gives
+    // the right +-1; the test is on the whole utterance, not on this part, so the choice does not depend on how the
+    // attention is split). A step whose |q| reaches 40 reads the plain keys from global memory instead. As many of
+    // the part's rows as fit are staged (E_k or k); the others are read from L2 each step, E_k computed on the fly.
     bool keys_exp = false;
     if (att_on) {
-        if (a.lds_keys) {
+        {
+            const float4* ku = reinterpret_cast<const float4*>(a.keys + (size_t)b_att * a.T_in * 256);
             float kmax = 0.f;
-            for (int i = tid; i < t_n * 64; i += PD_THREADS) {
-                const float4 kv = reinterpret_cast<const float4*>(keys_g)[i];
+            for (int i = tid; i < a.T_in * 64; i += PD_THREADS) {
+                const float4 kv = ku[i];
                 kmax = fmaxf(fmaxf(kmax, fmaxf(fabsf(kv.x), fabsf(kv.y))), fmaxf(fabsf(kv.z), fabsf(kv.w)));
             }
             kmax = wave_max(kmax);
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
             kmax = fmaxf(fmaxf(wsum_s[4], wsum_s[5]), fmaxf(wsum_s[6], wsum_s[7]));
             keys_exp = kmax < 40.f;      // (NaN keys fail the test and keep the plain path)
             constexpr float c2 = 2.8853900817779268f;
-            for (int i = tid; i < t_n * 64; i += PD_THREADS) {
+            for (int i = tid; i < kl * 64; i += PD_THREADS) {
                 float4 kv = reinterpret_cast<const float4*>(keys_g)[i];
                 if (keys_exp)
                     kv = make_float4(__builtin_amdgcn_exp2f(kv.x * c2), __builtin_amdgcn_exp2f(kv.y * c2),
@@ -502,15 +506,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
                 const f32x4 eq = {__builtin_amdgcn_exp2f(qq.x * c2), __builtin_amdgcn_exp2f(qq.y * c2),
                                   __builtin_amdgcn_exp2f(qq.z * c2), __builtin_amdgcn_exp2f(qq.w * c2)};
                 const float sv = (v_att.x + v_att.y) + (v_att.z + v_att.w);
-                const float4* kp = reinterpret_cast<const float4*>(keys_s);
-                const int tw0 = wave < t_n ? wave : 0;                 // (a part may have fewer rows than waves)
-                float4 k0 = kp[tw0 * 64 + lane];
-                float4 k1 = kp[(wave + PD_WAVES < t_n ? wave + PD_WAVES : tw0) * 64 + lane];
-                for (int t = wave; t < t_n; t += 2 * PD_WAVES) {
-                    const int t1 = t + PD_WAVES, tn = t + 2 * PD_WAVES, tn1 = tn + PD_WAVES;
-                    // next pair's keys in flight under this pair's arithmetic
-                    const float4 n0 = kp[(tn < t_n ? tn : t) * 64 + lane];
-                    const float4 n1 = kp[(tn1 < t_n ? tn1 : t) * 64 + lane];
+                auto escore2 = [&](const float4 k0, const float4 k1, int t, int t1) {     // k0, k1: E_k of rows t, t1
                     float s0 = v_att.x * __builtin_amdgcn_rcpf(fmaf(k0.x, eq.x, 1.f)) + v_att.y * __builtin_amdgcn_rcpf(fmaf(k0.y, eq.y, 1.f)) +
                                v_att.z * __builtin_amdgcn_rcpf(fmaf(k0.z, eq.z, 1.f)) + v_att.w * __builtin_amdgcn_rcpf(fmaf(k0.w, eq.w, 1.f));
                     float s1 = v_att.x * __builtin_amdgcn_rcpf(fmaf(k1.x, eq.x, 1.f)) + v_att.y * __builtin_amdgcn_rcpf(fmaf(k1.y, eq.y, 1.f)) +
@@ -521,20 +517,51 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
                         e_s[t_lo + t] = s0;
                         if (t1 < t_n) e_s[t_lo + t1] = s1;
                     }
-                    k0 = n0;
-                    k1 = n1;
+                };
+                if (kl > 0) {
+                    const float4* kp = reinterpret_cast<const float4*>(keys_s);
+                    const int tw0 = wave < kl ? wave : 0;                  // (a part may have fewer rows than waves)
+                    float4 k0 = kp[tw0 * 64 + lane];
+                    float4 k1 = kp[(wave + PD_WAVES < kl ? wave + PD_WAVES : tw0) * 64 + lane];
+                    for (int t = wave; t < kl; t += 2 * PD_WAVES) {
+                        const int t1 = t + PD_WAVES, tn = t + 2 * PD_WAVES, tn1 = tn + PD_WAVES;
+                        // next pair's keys in flight under this pair's arithmetic
+                        const float4 n0 = kp[(tn < kl ? tn : t) * 64 + lane];
+                        const float4 n1 = kp[(tn1 < kl ? tn1 : t) * 64 + lane];
+                        escore2(k0, t1 < kl ? k1 : k0, t, t1 < kl ? t1 : t_n);
+                        k0 = n0;
+                        k1 = n1;
+                    }
                 }
-            } else if (a.lds_keys && !keys_exp) {
-                const float4* kp = reinterpret_cast<const float4*>(keys_s);
-                for (int t = wave; t < t_n; t += 2 * PD_WAVES) {
-                    const int t1 = t + PD_WAVES;
-                    score2(kp[t * 64 + lane], kp[(t1 < t_n ? t1 : t) * 64 + lane], t, t1);
+                {
+                    // rows beyond the staged ones: same arithmetic, E_k from the plain key in L2
+                    const float4* kp = reinterpret_cast<const float4*>(keys_g);
+                    auto ek = [&](int t) {
+                        const float4 kv = kp[t * 64 + lane];
+                        return make_float4(__builtin_amdgcn_exp2f(kv.x * c2), __builtin_amdgcn_exp2f(kv.y * c2),
+                                           __builtin_amdgcn_exp2f(kv.z * c2), __builtin_amdgcn_exp2f(kv.w * c2));
+                    };
+                    for (int t = kl + wave; t < t_n; t += 2 * PD_WAVES) {
+                        const int t1 = t + PD_WAVES;
+                        escore2(ek(t), ek(t1 < t_n ? t1 : t), t, t1);
+                    }
                 }
             } else {
-                const float4* kp = reinterpret_cast<const float4*>(keys_g);
-                for (int t = wave; t < t_n; t += 2 * PD_WAVES) {
-                    const int t1 = t + PD_WAVES;
-                    score2(kp[t * 64 + lane], kp[(t1 < t_n ? t1 : t) * 64 + lane], t, t1);
+                // plain path: staged rows when LDS holds the plain keys, global memory otherwise
+                const int kls = keys_exp ? 0 : kl;
+                {
+                    const float4* kp = reinterpret_cast<const float4*>(keys_s);
+                    for (int t = wave; t < kls; t += 2 * PD_WAVES) {
+                        const int t1 = t + PD_WAVES;
+                        score2(kp[t * 64 + lane], kp[(t1 < kls ? t1 : t) * 64 + lane], t, t1 < kls ? t1 : t_n);
+                    }
+                }
+                {
+                    const float4* kp = reinterpret_cast<const float4*>(keys_g);
+                    for (int t = kls + wave; t < t_n; t += 2 * PD_WAVES) {
+                        const int t1 = t + PD_WAVES;
+                        score2(kp[t * 64 + lane], kp[(t1 < t_n ? t1 : t) * 64 + lane], t, t1);
+                    }
                 }
             }
             __syncthreads();
@@ -699,10 +726,12 @@ size_t dec_persistent_lds_bytes(int T_in, int B, int* lds_keys, int* lds_vals) {
     const int T4 = (T_in + 3) & ~3, Tp = (T_in + P - 1) / P;
     size_t base = 8192 + (size_t)ST_COUNT * 16 * 4 + (size_t)T4 * 8 + 32;
     base = (base + 15) & ~(size_t)15;
-    const size_t kb = (size_t)Tp * 1024, vb = (size_t)T_in * (256 / P) * 4;
-    *lds_keys = base + kb <= cap;
-    *lds_vals = base + (*lds_keys ? kb : 0) + vb <= cap;
-    return base + (*lds_keys ? kb : 0) + (*lds_vals ? vb : 0);
+    const size_t vb = (size_t)T_in * (256 / P) * 4;
+    const int rows_fit = (int)((cap - base) / 1024);
+    *lds_keys = Tp < rows_fit ? Tp : rows_fit;                       // key rows of a part held in LDS
+    const size_t kb = (size_t)*lds_keys * 1024;
+    *lds_vals = *lds_keys == Tp && base + kb + vb <= cap;
+    return base + kb + (*lds_vals ? vb : 0);
 }
 
 int launch_dec_persistent(DecPersistArgs a, hipStream_t s, Timing* tm) {

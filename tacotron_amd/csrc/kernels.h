@@ -137,7 +137,7 @@ struct DecPersistArgs {
     float* alignS;            // [S][B][T_in]
     unsigned long long* sync; // {unused, abort word}, zeroed per call
     int B, Bpad, T_in, S;
-    int lds_keys, lds_vals;   // filled by the launcher
+    int lds_keys, lds_vals;   // filled by the launcher: key rows per attention part staged in LDS, values staged or not
     unsigned long long* dbg;  // diagnostic builds (-DPD_STAMPS): s_memrealtime stamps of workgroup 0, step 5
 };
 int launch_dec_persistent(DecPersistArgs a, hipStream_t s, Timing* tm);

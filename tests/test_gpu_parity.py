@@ -422,3 +422,19 @@ def test_hip_path_matches_committed_goldens():
         assert np.linalg.norm(wav - g['gl_wav']) / np.linalg.norm(g['gl_wav']) < 1e-4
     finally:
         eng.close()
+
+
+def test_decode_long_input_split_invariance(engine, hp, weights):
+    """Long inputs (T_in = 400: a full tile's key parts no longer fit in LDS, so part of the rows is scored from L2)
+    and the attention split that follows the batch size (32 workgroups per utterance alone, 8 in a batch of 3, 2 in a
+    full tile): parity with the oracle, and the same utterance bit-identical in every batch."""
+    import torch
+    rng = np.random.default_rng(21)
+    enc = (0.5 * rng.standard_normal((18, 400, 256))).astype(np.float32)
+    _check_decode(engine, hp, weights, enc[:2].astype(np.float64), 3, 'decode B=2 T_in=400')
+    m_all, a_all, _ = engine.decode(enc, max_iters=4)
+    for lo, hi in [(0, 1), (0, 3), (5, 10), (16, 18)]:
+        m, a, _ = engine.decode(enc[lo:hi], max_iters=4)
+        assert torch.equal(m, m_all[lo:hi]) and torch.equal(a, a_all[lo:hi]), (lo, hi)
+    ref = O.decode(enc[16:18].astype(np.float64), O.cast_weights(weights, np.float64), hp, max_iters=4)
+    assert rel_l1(_np(m_all[16:18]), ref[0]) < 1e-3
