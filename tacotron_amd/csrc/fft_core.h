@@ -19,6 +19,16 @@
 
 namespace taco {
 
+#if defined(__HIPCC__)
+// (re, im) as one two-float vector: a complex add is one packed instruction on the pair, a complex multiply two
+// (packed multiply + packed FMA with swizzled operands); left as a struct of two floats the vectoriser pairs
+// components of different elements instead and pays for it in register moves
+typedef float cplx __attribute__((ext_vector_type(2)));
+TACO_HD cplx cadd(cplx a, cplx b) { return a + b; }
+TACO_HD cplx csub(cplx a, cplx b) { return a - b; }
+TACO_HD cplx cmul(cplx a, cplx b) { return __builtin_elementwise_fma(a.yy, cplx{-b.y, b.x}, a.xx * b); }
+TACO_HD cplx cconj(cplx a) { return cplx{a.x, -a.y}; }
+#else
 struct cplx {
     float x, y;
 };
@@ -26,6 +36,7 @@ TACO_HD cplx cadd(cplx a, cplx b) { return {a.x + b.x, a.y + b.y}; }
 TACO_HD cplx csub(cplx a, cplx b) { return {a.x - b.x, a.y - b.y}; }
 TACO_HD cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 TACO_HD cplx cconj(cplx a) { return {a.x, -a.y}; }
+#endif
 
 constexpr int FFT_N = 1024;                 // complex length
 constexpr int FFT_LANES = 64;               // one wave

@@ -243,8 +243,8 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __r
                     y0 = LIBROSA ? start(mk[0], 0).x : mk[0];
                     yn = LIBROSA ? start(mn[0], FFT_N).x : mn[0];
                 } else {
-                    y0 = rephase({v[0].x + v[0].y, 0.f}, mk[0]).x;
-                    yn = rephase({v[0].x - v[0].y, 0.f}, mn[0]).x;
+                    y0 = rephase(cplx{v[0].x + v[0].y, 0.f}, mk[0]).x;
+                    yn = rephase(cplx{v[0].x - v[0].y, 0.f}, mn[0]).x;
                 }
                 v[0] = {0.5f * (y0 + yn), 0.5f * (y0 - yn)};
                 // bin 512 pairs with itself: X512 = conj(Z512); Z'512 = conj(Y512)
