@@ -182,10 +182,17 @@ TACO_HD void fft_pass3(cplx (&v)[16], int lane, const cplx* T3) {
 
 // Split step of the real transform for the bin pair (k, 1024-k), 1 <= k <= 511:
 // from Z = FFT1024(z) to the real-signal spectrum X[k], X[1024-k].
+#if defined(__HIPCC__)
+TACO_HD cplx chalf_sum(cplx a, cplx b) { return 0.5f * (a + b); }
+TACO_HD cplx chalf_diff(cplx a, cplx b) { return 0.5f * (a - b); }
+#else
+TACO_HD cplx chalf_sum(cplx a, cplx b) { return {0.5f * (a.x + b.x), 0.5f * (a.y + b.y)}; }
+TACO_HD cplx chalf_diff(cplx a, cplx b) { return {0.5f * (a.x - b.x), 0.5f * (a.y - b.y)}; }
+#endif
 TACO_HD void rfft_split(cplx Zk, cplx Zn, cplx Wk, cplx& Xk, cplx& Xn) {
     const cplx cn = cconj(Zn);
-    const cplx E = {0.5f * (Zk.x + cn.x), 0.5f * (Zk.y + cn.y)};
-    const cplx D = {0.5f * (Zk.x - cn.x), 0.5f * (Zk.y - cn.y)};
+    const cplx E = chalf_sum(Zk, cn);
+    const cplx D = chalf_diff(Zk, cn);
     const cplx O = {D.y, -D.x};              // D / i
     const cplx P = cmul(Wk, O);
     Xk = cadd(E, P);
@@ -196,8 +203,8 @@ TACO_HD void rfft_split(cplx Zk, cplx Zn, cplx Wk, cplx& Xk, cplx& Xn) {
 // (x[2m] = Re z'[m] / 1024, x[2m+1] = Im z'[m] / 1024).
 TACO_HD void irfft_merge(cplx Yk, cplx Yn, cplx Wk, cplx& Zk, cplx& Zn) {
     const cplx cn = cconj(Yn);
-    const cplx E = {0.5f * (Yk.x + cn.x), 0.5f * (Yk.y + cn.y)};
-    const cplx D = {0.5f * (Yk.x - cn.x), 0.5f * (Yk.y - cn.y)};
+    const cplx E = chalf_sum(Yk, cn);
+    const cplx D = chalf_diff(Yk, cn);
     const cplx O = cmul(D, cconj(Wk));
     const cplx iO = {-O.y, O.x};
     Zk = cadd(E, iO);
@@ -211,6 +218,7 @@ TACO_HD cplx gl_rephase(cplx X, float mag) {
     // sqrt and divide sequences (~20 instructions each, 17 bins per lane and frame)
     const float a2 = __builtin_fmaf(X.x, X.x, X.y * X.y);
     const float s = mag * __builtin_amdgcn_rsqf(a2 > 1e-16f ? a2 : 1e-16f);
+    return X * s;
 #else
     const float a = __builtin_sqrtf(X.x * X.x + X.y * X.y);
     const float s = mag / (a > 1e-8f ? a : 1e-8f);
