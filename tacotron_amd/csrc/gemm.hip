@@ -32,12 +32,12 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
-    constexpr int BK = 16, PAD = 4;
+    constexpr int BK = 16, PAD = 4, APAD = 2;   // A rows: stride 130 puts the four k-quads of a stash on banks 8 apart
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NA = BM * 4 / 256;          // float4 A loads per thread per tile
     constexpr int NB = BK * BN / 4 / 256;     // float4 B loads per thread per tile
-    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + PAD];
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + APAD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PAD];
 
     const int tid = threadIdx.x;
