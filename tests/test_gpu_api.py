@@ -293,3 +293,30 @@ def test_c_abi_error_paths(engine, hp, weights):
     # the handle still works
     ref = O.encode(ids, lens, weights, hp)
     assert rel_l1(_np(engine.encode(ids, lens)), ref) < 1e-3
+
+
+@pytest.mark.parametrize('overrides', [
+    dict(outputs_per_step=3, encoder_K=5, decoder_K=4, encoder_num_highway_layers=2, decoder_num_highway_layers=3),
+    dict(prenet_depths=[128, 64], attention_depth=128, decoder_depth=128, postnet_depth=128, embedded_depth=128,
+         encoder_bank_num_filters=64, decoder_bank_num_filters=96, encoder_proj_num_filters=[96, 64],
+         decoder_proj_num_filters=[128, 80], encoder_highway_depth=64, decoder_highway_depth=96, outputs_per_step=2),
+])
+def test_non_default_hparams(overrides):
+    """The reference's layer sizes are hparams (`--hparams k=v`): a model with other sizes runs through the general
+    kernels (the persistent decoder is specialised to the default sizes and steps aside) and matches the oracle."""
+    from tacotron_amd.engine import TacoEngine
+    from tacotron_amd.hparams import HParams
+    from tacotron_amd.weights import init_weights
+    hp2 = HParams(max_iters=5, griffin_lim_iters=2, **overrides)
+    w = init_weights(hp2, seed=77, randomize_bn=True, randomize_bias=True)
+    ids, lens = synth_ids(np.random.default_rng(5), 3, 13)
+    ref = O.tacotron_forward(ids, lens, w, hp2)
+    eng = TacoEngine(w, hp2)
+    try:
+        o = eng.finish(eng.synthesize(ids, lens, max_iters=5))
+        r = hp2.outputs_per_step
+        assert tuple(o['mel'].shape) == (3, 5 * r, hp2.num_mels) and o['steps_run'] == 5
+        for name in ('enc_out', 'mel', 'linear', 'alignments'):
+            assert rel_l1(_np(o[name]), ref[name]) < 1e-3, name
+    finally:
+        eng.close()
