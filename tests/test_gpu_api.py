@@ -320,3 +320,30 @@ def test_non_default_hparams(overrides):
             assert rel_l1(_np(o[name]), ref[name]) < 1e-3, name
     finally:
         eng.close()
+
+
+def test_non_default_frame_geometry(weights):
+    """frame_shift_ms / frame_length_ms are hparams (hop 240, window 960 here instead of 300 / 1200): the Griffin-Lim
+    and STFT kernels' run-time-geometry instantiations against the oracle."""
+    from tacotron_amd.engine import TacoEngine
+    from tacotron_amd.hparams import HParams
+    hp2 = HParams(frame_shift_ms=10, frame_length_ms=40)
+    assert hp2.stft_params() == (2048, 240, 960)
+    eng = TacoEngine(weights, hp2)
+    try:
+        rng = np.random.default_rng(12)
+        lin = rng.uniform(0.3, 1.0, size=(2, 23, 1025)).astype(np.float32)
+        ref = O.spectrogram_tensorflow_inv(lin.astype(np.float64), hp2, iters=3)
+        got = _np(eng.griffin_lim(lin, iters=3))
+        assert got.shape == ref.shape == (2, 22 * 240 + 960)
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-3
+        u = rng.random((2, 23, 1025))
+        ref = np.stack([O.griffin_lim_librosa(lin[b].T.astype(np.float64), hp2, u[b].T, 2) for b in range(2)])
+        got = _np(eng.griffin_lim_librosa(lin, u.astype(np.float32), iters=2))
+        assert got.shape == ref.shape and np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-3
+        y = (0.1 * rng.standard_normal(5000)).astype(np.float32)
+        l, m = eng.spectrogram(y)
+        assert np.abs(_np(l)[0].T - O.spectrogram_librosa(y.astype(np.float64), hp2)).max() < 2e-3
+        assert np.abs(_np(m)[0].T - O.mel_spectrogram_librosa(y.astype(np.float64), hp2)).max() < 2e-3
+    finally:
+        eng.close()
