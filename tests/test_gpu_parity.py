@@ -438,3 +438,32 @@ def test_decode_long_input_split_invariance(engine, hp, weights):
         assert torch.equal(m, m_all[lo:hi]) and torch.equal(a, a_all[lo:hi]), (lo, hi)
     ref = O.decode(enc[16:18].astype(np.float64), O.cast_weights(weights, np.float64), hp, max_iters=4)
     assert rel_l1(_np(m_all[16:18]), ref[0]) < 1e-3
+
+
+@pytest.mark.parametrize('B,T_in,S', [(1, 1, 1), (2, 2, 2), (3, 3, 1)])
+def test_minimum_sizes(engine, hp, weights, B, T_in, S):
+    """One-character inputs, one decoder step: every stage at its smallest size (conv banks wider than the sequence,
+    attention parts without rows, a single Griffin-Lim frame run)."""
+    rng = np.random.default_rng(B + 10 * T_in)
+    ids, lens = synth_ids(rng, B, T_in, min_len=1)
+    ref = O.tacotron_forward(ids, lens, weights, hp, max_iters=S)
+    o = engine.finish(engine.synthesize(ids, lens, max_iters=S, to_wav=True, gl_iters=2), to_wav=True, gl_iters=2)
+    assert o['steps_run'] == S
+    for name in ('enc_out', 'mel', 'linear', 'alignments'):
+        assert rel_l1(_np(o[name]), ref[name]) < 1e-3, name
+    wav_ref = O.spectrogram_tensorflow_inv(ref['linear'], hp, iters=2)
+    assert np.linalg.norm(_np(o['wav']) - wav_ref) / np.linalg.norm(wav_ref) < 1e-3
+
+
+@pytest.mark.parametrize('B', [128, 130])
+def test_decode_large_batch(engine, hp, weights, B):
+    """B = 128 is the persistent decoder's largest launch (8 batch tiles, all 256 CUs); beyond it the decode takes
+    the per-stage kernels. Both against the oracle on a few utterances, and consistent across the boundary."""
+    rng = np.random.default_rng(B)
+    enc = (0.5 * rng.standard_normal((B, 12, 256))).astype(np.float32)
+    mel, al, steps = engine.decode(enc, max_iters=3)
+    engine.decode_status()
+    assert int(_np(steps)[0]) == 3
+    pick = [0, 77, B - 1]
+    ref = O.decode(enc[pick].astype(np.float64), O.cast_weights(weights, np.float64), hp, max_iters=3)
+    assert rel_l1(_np(mel)[pick], ref[0]) < 1e-3 and rel_l1(_np(al)[pick], ref[1]) < 1e-3
