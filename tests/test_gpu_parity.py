@@ -467,3 +467,14 @@ def test_decode_large_batch(engine, hp, weights, B):
     pick = [0, 77, B - 1]
     ref = O.decode(enc[pick].astype(np.float64), O.cast_weights(weights, np.float64), hp, max_iters=3)
     assert rel_l1(_np(mel)[pick], ref[0]) < 1e-3 and rel_l1(_np(al)[pick], ref[1]) < 1e-3
+
+
+def test_very_long_input(engine, hp, weights):
+    """T_in = 1000 characters (far beyond the reference's own utterances): encoder, decoder with most key rows and
+    all values read from L2, alignments [B, 1000, S]."""
+    rng = np.random.default_rng(31)
+    ids, lens = synth_ids(rng, 2, 1000)
+    ref = O.tacotron_forward(ids, lens, weights, hp, max_iters=2)
+    o = engine.finish(engine.synthesize(ids, lens, max_iters=2))
+    for name in ('enc_out', 'mel', 'linear', 'alignments'):
+        assert rel_l1(_np(o[name]), ref[name]) < 1e-3, name
