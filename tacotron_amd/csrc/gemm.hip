@@ -8,8 +8,9 @@
 // loader of the following projection conv.
 //
 // Tiling: BMxBN block, 256 threads = 2x2 waves, each wave (BM/2)x(BN/2) as 32x32 MFMA
-// tiles; BK = 16 staged through LDS k-major so that the one-VGPR A/B fragments
-// (lane l: A[m=l&31][k=l>>5], B[k=l>>5][n=l&31]) are conflict-free ds_read_b32.
+// tiles; BK = 16 staged through LDS: A row-major as it is loaded (row stride 20 floats), a lane's
+// eight k values of a tile in two ds_read_b128 (lane half lk feeds k = 8 lk + kk to MFMA kk); B k-major,
+// one conflict-free ds_read_b32 per fragment (lane l: B[k][n = l & 31]).
 // Global->register prefetch of tile k+1 overlaps the MFMAs of tile k (one barrier per tile).
 #include "kernels.h"
 
@@ -32,12 +33,12 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
-    constexpr int BK = 16, PAD = 4, APAD = 2;   // A rows: stride 130 puts the four k-quads of a stash on banks 8 apart
+    constexpr int BK = 16, PAD = 4, AST = BK + 4;   // A row stride 20: the 16 lanes of a ds_read_b128 group hit 16 bank quads
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NA = BM * 4 / 256;          // float4 A loads per thread per tile
     constexpr int NB = BK * BN / 4 / 256;     // float4 B loads per thread per tile
-    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + APAD];
+    __shared__ __attribute__((aligned(16))) float As[2][BM][AST];     // row-major: stashed as it is loaded (16 bytes along k)
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PAD];
 
     const int tid = threadIdx.x;
@@ -126,10 +127,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
             const int row = f >> 2, k = 4 * (f & 3);                                                     \
             f32x4v v = ra[i];                                                                            \
             if (a.pool) v = __builtin_elementwise_max(v, rp[i]);                                         \
-            As[buf][k + 0][row] = v.x;                                                                   \
-            As[buf][k + 1][row] = v.y;                                                                   \
-            As[buf][k + 2][row] = v.z;                                                                   \
-            As[buf][k + 3][row] = v.w;                                                                   \
+            *reinterpret_cast<f32x4v*>(&As[buf][row][k]) = v;                                            \
         }                                                                                                \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                 \
             const int f = tid + 256 * i;                                                                 \
@@ -147,23 +145,29 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int lk = lane >> 5, li = lane & 31;
-    // fragments of k-pair kk+1 are read from LDS while the MFMAs of k-pair kk run
+    // The k index a lane half feeds to MFMA kk of a tile is 8 lk + kk (A and B alike; any fixed pairing of the 16 k's
+    // is a valid order of the sum): a lane's eight A values are then contiguous in its row, two ds_read_b128.
+    // B fragments of k-pair kk+2 are read from LDS while the MFMAs of k-pair kk run.
 #define CG_COMPUTE(buf)                                                                                  \
     do {                                                                                                 \
         float af[BK / 2][TM], bf[BK / 2][TN];                                                            \
-        _Pragma("unroll") for (int kk = 0; kk < BK / 2; ++kk) {                                          \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) af[kk][i] = As[buf][2 * kk + lk][wm + 32 * i + li]; \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[kk][j] = Bs[buf][2 * kk + lk][wn + 32 * j + li]; \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                 \
+            const f32x4v a0 = *reinterpret_cast<const f32x4v*>(&As[buf][wm + 32 * i + li][8 * lk]);     \
+            const f32x4v a1 = *reinterpret_cast<const f32x4v*>(&As[buf][wm + 32 * i + li][8 * lk + 4]); \
+            af[0][i] = a0.x; af[1][i] = a0.y; af[2][i] = a0.z; af[3][i] = a0.w;                          \
+            af[4][i] = a1.x; af[5][i] = a1.y; af[6][i] = a1.z; af[7][i] = a1.w;                          \
         }                                                                                                \
+        _Pragma("unroll") for (int kk = 0; kk < BK / 2; ++kk)                                            \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[kk][j] = Bs[buf][8 * lk + kk][wn + 32 * j + li]; \
         _Pragma("unroll") for (int kk = 0; kk < BK / 2; ++kk)                                            \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                               \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                           \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0); \
-        /* issue order: the LDS reads of k-pair kk+2 go out before the MFMAs of k-pair kk */             \
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                               \
+        /* issue order: all A reads and the B reads of two k-pairs first, then B of k-pair kk+2 before the MFMAs of kk */ \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM + 2 * TN, 0);                                 \
         _Pragma("unroll") for (int kk = 0; kk < BK / 2; ++kk) {                                          \
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                                     \
-            if (kk + 2 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                      \
+            if (kk + 2 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, TN, 0);                     \
         }                                                                                                \
     } while (0)
 
