@@ -162,6 +162,11 @@ def main():
         ndev = torch.cuda.device_count()
         if backend == 'nccl' and local >= ndev:
             raise SystemExit('rank %d: LOCAL_RANK %d but only %d GPUs visible' % (rank, local, ndev))
+        if world > max(ndev, 1):
+            # rehearsal only: ranks share a GPU, and the persistent decoder's CU budget is per process - keep the
+            # decodes in flight on one device within the chip (4 x 64 CUs) so that they cannot wait on each other
+            per_gpu = -(-world // max(ndev, 1))
+            args.streams = max(1, min(args.streams, 4 // per_gpu))
         local = local % max(ndev, 1)
         torch.cuda.set_device(local)
         if backend == 'nccl':
