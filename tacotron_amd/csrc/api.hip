@@ -1204,6 +1204,13 @@ extern "C" int taco_decode_status(taco_handle h) {
     unsigned info[4] = {0, 0, 0, 0};
     HIP_OK(hipMemcpy(info, h->sync_words, 16, hipMemcpyDeviceToHost));
     w = (unsigned long long)info[1] << 32;
+#ifdef PD_PHASE_STAMPS
+    {
+        unsigned long long st[3];
+        HIP_OK(hipMemcpy(st, reinterpret_cast<unsigned long long*>(h->sync_words) + 8, sizeof(st), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pd phases] entry->step0 %.1f us, steps 1.. %.1f us\n", (st[1] - st[0]) * 0.01, (st[2] - st[1]) * 0.01);
+    }
+#endif
 #ifdef PD_STAMPS
     if (h->dbg_stamps) {
         unsigned long long st[256];

@@ -290,6 +290,9 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bt = blockIdx.x >> 5, j = blockIdx.x & 31;
+#ifdef PD_PHASE_STAMPS   // diagnostic build: when did workgroup 0 start, finish step 0 (everybody resident), finish
+    if (blockIdx.x == 0 && tid == 0) reinterpret_cast<unsigned long long*>(a.sync)[8] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int b0 = bt * 16, Bpad = a.Bpad;
     const int lb = b0 + (lane & 15), lq = lane >> 4;
     const bool col_on = lb < a.B;            // this lane's batch column is a real utterance
@@ -708,6 +711,10 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
         if (spin.stamp_on && tid == 0)
             for (int i = 0; i < spin.stamp_i; ++i) a.dbg[i] = spin.st_lds[i];
         spin.stamp_on = false;
+#endif
+#ifdef PD_PHASE_STAMPS
+        if (blockIdx.x == 0 && tid == 0 && (s == 0 || s == a.S - 1))
+            reinterpret_cast<unsigned long long*>(a.sync)[s == 0 ? 9 : 10] = __builtin_amdgcn_s_memrealtime();
 #endif
     }
     {
