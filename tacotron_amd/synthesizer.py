@@ -41,6 +41,7 @@ class Synthesizer:
             raise FileNotFoundError('neither %s.index (TF checkpoint) nor %s.npz found' % (restore_dir, restore_dir))
         self._weights, self._device = weights, device
         self.model = Tacotron(hparams=hparams, weights=weights, device=device)
+        audio.set_default_engine(self.model.engine)
         return self
 
     def load_random(self, seed=1234, device=0):

@@ -1,5 +1,7 @@
 """Audio tools of the synthesis path (reference tools/audio.py).
 
+Every function keeps the reference's signature; the optional `engine` argument (default: the engine registered by
+`Synthesizer.load`, or one created on first use) names the GPU handle to run on.
 Device side: `spectrogram_tensorflow_inv` (audio.py:57-64) runs the HIP Griffin-Lim
 (taco_griffin_lim). Host side, as in the reference (synthesizer.py:44-57): `pre_emphasis_inv`
 (audio.py:111-116), `find_endpoint` (audio.py:81-88), `save_wav` (audio.py:15-17). `spectrogram_inv` (audio.py:44-55,
@@ -15,23 +17,44 @@ import numpy as np
 from ..hparams import hparams
 
 
-def spectrogram_tensorflow_inv(spect, engine, iters=None):
+_default_engine = None
+
+
+def set_default_engine(engine):
+    """The engine the functions below use when none is passed, so that they can be called with the reference's own
+    signatures (`audio.spectrogram(y)`, `audio.spectrogram_inv(spect)`); `Synthesizer.load` registers its model's."""
+    global _default_engine
+    _default_engine = engine
+
+
+def default_engine():
+    """The registered engine, or one created on first use: the audio kernels need no trained weights, only a handle
+    (hparams + the derived mel filterbank), so randomly initialised ones do."""
+    global _default_engine
+    if _default_engine is None or getattr(_default_engine, 'handle', None) is None:     # none yet, or closed
+        from ..engine import TacoEngine
+        from ..weights import init_weights
+        _default_engine = TacoEngine(init_weights(hparams, seed=0), hparams)
+    return _default_engine
+
+
+def spectrogram_tensorflow_inv(spect, engine=None, iters=None):
     """[T, 1025] or [B, T, 1025] normalised linear spectrogram -> waveform(s) on the GPU.
     Does NOT invert the pre-emphasis (the caller does, as synthesizer.py:44)."""
-    return engine.griffin_lim(spect, iters)
+    return (engine or default_engine()).griffin_lim(spect, iters)
 
 
 inv_spectrogram = spectrogram_tensorflow_inv
 
 
-def spectrogram_inv(spect, engine, iters=None, rng=None):
+def spectrogram_inv(spect, engine=None, iters=None, rng=None):
     """audio.py:44-55: [num_freq, T] normalised linear spectrogram (the reference passes `spectrogram.T`) -> waveform
     [hop * (T - 1)] float64, numpy/librosa-flavoured Griffin-Lim on the GPU (taco_griffin_lim_librosa) and the
     de-emphasis on the host. The initial phases are np.random.rand(*spect.shape) as at audio.py:175 (global numpy
     state, so np.random.seed reproduces the reference's draw), or rng.random(spect.shape) when a Generator is given."""
     spect = np.asarray(spect)
     u = np.random.rand(*spect.shape) if rng is None else rng.random(spect.shape)
-    y = engine.griffin_lim_librosa(np.ascontiguousarray(spect.T, np.float32), np.ascontiguousarray(u.T, np.float32),
+    y = (engine or default_engine()).griffin_lim_librosa(np.ascontiguousarray(spect.T, np.float32), np.ascontiguousarray(u.T, np.float32),
                                    iters)
     return pre_emphasis_inv(y.cpu().numpy())
 
@@ -73,15 +96,15 @@ def build_mel_basis(hp=None):
     return weights.astype(np.float32)
 
 
-def spectrogram(y, engine):
+def spectrogram(y, engine=None):
     """audio.py:23-42: normalised linear-scale dB spectrogram [1 + n_fft/2, frames] of one waveform."""
-    lin, _ = engine.spectrogram(np.asarray(y, np.float32)[None], want_mel=False)
+    lin, _ = (engine or default_engine()).spectrogram(np.asarray(y, np.float32)[None], want_mel=False)
     return lin[0].T.cpu().numpy()
 
 
-def mel_spectrogram(y, engine):
+def mel_spectrogram(y, engine=None):
     """audio.py:66-79: normalised mel-scale dB spectrogram [num_mels, frames]."""
-    _, mel = engine.spectrogram(np.asarray(y, np.float32)[None], want_linear=False)
+    _, mel = (engine or default_engine()).spectrogram(np.asarray(y, np.float32)[None], want_linear=False)
     return mel[0].T.cpu().numpy()
 
 

@@ -347,3 +347,23 @@ def test_non_default_frame_geometry(weights):
         assert np.abs(_np(m)[0].T - O.mel_spectrogram_librosa(y.astype(np.float64), hp2)).max() < 2e-3
     finally:
         eng.close()
+
+
+def test_audio_tools_reference_signatures(hp):
+    """tools.audio with the reference's own call shapes (no engine argument): spectrogram(y), mel_spectrogram(y),
+    spectrogram_inv(spect), inv_spectrogram(spect) run on the default engine."""
+    from tacotron_amd.tools import audio
+    rng = np.random.default_rng(3)
+    y = (0.1 * rng.standard_normal(6000)).astype(np.float32)
+    lin = audio.spectrogram(y)
+    mel = audio.mel_spectrogram(y)
+    assert lin.shape == (1025, 21) and mel.shape == (80, 21)
+    assert np.abs(lin - O.spectrogram_librosa(y.astype(np.float64), hp)).max() < 2e-3
+    np.random.seed(7)
+    wav = audio.spectrogram_inv(lin)
+    np.random.seed(7)
+    u = np.random.rand(1025, 21)
+    ref = O.pre_emphasis_inv(O.griffin_lim_librosa(lin.astype(np.float64), hp, u), hp.preemphasis)
+    assert wav.shape == ref.shape == (20 * 300,) and np.linalg.norm(wav - ref) / np.linalg.norm(ref) < 2e-2
+    w2 = audio.inv_spectrogram(lin.T)
+    assert tuple(w2.shape) == (20 * 300 + 1200,)
