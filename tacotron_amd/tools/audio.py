@@ -9,7 +9,8 @@ the numpy/librosa Griffin-Lim train.py uses for evaluation audio) runs taco_grif
 Analysis half (audio.py:23-42,66-79: what data/data_load.py:114-146 stores as `*-spec-*.npy` / `*-mel-*.npy`):
 `spectrogram` / `mel_spectrogram` run the centred STFT, dB scaling and mel projection on the GPU
 (taco_spectrogram); `build_mel_basis` restates librosa.filters.mel (librosa 0.5.1: Slaney scale, area-normalised)
-on the host - librosa is not installed here, so that restatement is unpinned. load_wav / trim_silence stay out."""
+on the host - librosa is not installed here, so that restatement is unpinned. `load_wav` reads PCM WAV with the
+standard library, `trim_silence` restates librosa.effects.trim (unpinned)."""
 import wave
 
 import numpy as np
@@ -94,6 +95,48 @@ def build_mel_basis(hp=None):
     weights = np.maximum(0.0, np.minimum(lower, upper))
     weights *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
     return weights.astype(np.float32)
+
+
+def load_wav(path):
+    """audio.py:8-13 (librosa.core.load(path, sr=hparams.sample_rate)[0]): mono float32 waveform in [-1, 1] at the
+    model's sample rate. PCM WAV files are read with the standard library; a file at another rate is resampled with
+    scipy's polyphase filter, which is not librosa's resampler (unpinned; files at the model's rate are exact)."""
+    with wave.open(path, 'rb') as f:
+        ch, width, rate, n = f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()
+        raw = f.readframes(n)
+    if width == 2:
+        y = np.frombuffer(raw, '<i2').astype(np.float32) / 32768.0
+    elif width == 4:
+        y = np.frombuffer(raw, '<i4').astype(np.float32) / 2147483648.0
+    elif width == 1:
+        y = (np.frombuffer(raw, np.uint8).astype(np.float32) - 128.0) / 128.0
+    else:
+        raise ValueError('%s: unsupported sample width %d bytes' % (path, width))
+    if ch > 1:
+        y = y.reshape(-1, ch).mean(axis=1)                      # librosa's to_mono
+    sr = int(hparams.get('sample_rate'))
+    if rate != sr:
+        from math import gcd
+        from scipy import signal
+        g = gcd(sr, rate)
+        y = signal.resample_poly(y, sr // g, rate // g).astype(np.float32)
+    return y
+
+
+def trim_silence(audio_signal, top_db=60, frame_length=2048, hop_length=512):
+    """audio.py:19-21 (librosa.effects.trim, librosa 0.5.1 defaults, restated: unpinned): drop leading and trailing
+    frames whose mean square is more than top_db below the loudest frame's."""
+    y = np.asarray(audio_signal)
+    if len(y) < frame_length:
+        return y
+    nfr = 1 + (len(y) - frame_length) // hop_length
+    idx = hop_length * np.arange(nfr)[:, None] + np.arange(frame_length)[None, :]
+    mse = np.mean(np.square(y[idx].astype(np.float64)), axis=1)
+    db = 10.0 * np.log10(np.maximum(1e-10, mse)) - 10.0 * np.log10(max(1e-10, float(mse.max())))
+    nz = np.flatnonzero(db > -top_db)
+    if nz.size == 0:
+        return y[:0]
+    return y[int(nz[0]) * hop_length:min(len(y), (int(nz[-1]) + 1) * hop_length)]
 
 
 def spectrogram(y, engine=None):

@@ -126,3 +126,20 @@ def test_split_text_and_plot(tmp_path):
     path = str(tmp_path / 'a.png')
     plot_alignment(np.random.default_rng(0).random((20, 30)), path, info='step 7')
     assert open(path, 'rb').read(4) == b'\x89PNG'
+
+
+def test_wav_io_and_trim_silence(tmp_path):
+    from tacotron_amd.tools import audio
+    rng = np.random.default_rng(2)
+    y = 0.3 * np.sin(2 * np.pi * 220 * np.arange(24000) / 24000) + 0.01 * rng.standard_normal(24000)
+    path = str(tmp_path / 'a.wav')
+    audio.save_wav(y.copy(), path)
+    z = audio.load_wav(path)
+    assert z.dtype == np.float32 and z.shape == y.shape
+    assert np.allclose(z, y / np.abs(y).max(), atol=2e-4)           # save_wav scales to full range (audio.py:16)
+    # 0.5 s of digital silence on both sides is trimmed to the frame grid (hop 512)
+    padded = np.concatenate([np.zeros(12000), y, np.zeros(12000)]).astype(np.float32)
+    t = audio.trim_silence(padded)
+    assert 24000 <= len(t) <= 24000 + 2 * 2048 and abs(float(np.abs(t).max()) - float(np.abs(y).max())) < 1e-6
+    assert len(audio.trim_silence(np.zeros(5000, np.float32))) == 6 * 512       # all frames equal the reference level: kept, cut to the frame grid
+    assert np.array_equal(audio.trim_silence(y.astype(np.float32)[:100]), y.astype(np.float32)[:100])

@@ -367,3 +367,22 @@ def test_audio_tools_reference_signatures(hp):
     assert wav.shape == ref.shape == (20 * 300,) and np.linalg.norm(wav - ref) / np.linalg.norm(ref) < 2e-2
     w2 = audio.inv_spectrogram(lin.T)
     assert tuple(w2.shape) == (20 * 300 + 1200,)
+
+
+def test_process_utterance_writes_reference_format(tmp_path, hp):
+    """data/data_load.py:114-146: a wav file -> <prefix>-spec-%05d.npy [T, 1025] and <prefix>-mel-%05d.npy [T, 80],
+    float32, loadable without pickle; values against the oracle's librosa-flavoured analysis of the same samples."""
+    from tacotron_amd.data.data_load import process_utterance
+    from tacotron_amd.tools import audio
+    rng = np.random.default_rng(4)
+    y = 0.2 * np.sin(2 * np.pi * 330 * np.arange(9000) / 24000) + 0.02 * rng.standard_normal(9000)
+    wav_path = str(tmp_path / 'u.wav')
+    audio.save_wav(y.copy(), wav_path)
+    out = process_utterance(str(tmp_path), 7, wav_path, 'some text', prefix='ljs', speaker='a')
+    assert out == ('ljs-spec-00007.npy', 'ljs-mel-00007.npy', 31, 'some text', 'a')
+    spec = np.load(str(tmp_path / out[0]), allow_pickle=False)
+    mel = np.load(str(tmp_path / out[1]), allow_pickle=False)
+    assert spec.dtype == mel.dtype == np.float32 and spec.shape == (31, 1025) and mel.shape == (31, 80)
+    w = audio.load_wav(wav_path).astype(np.float64)
+    assert np.abs(spec.T - O.spectrogram_librosa(w, hp)).max() < 2e-3
+    assert np.abs(mel.T - O.mel_spectrogram_librosa(w, hp)).max() < 2e-3
