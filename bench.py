@@ -15,16 +15,27 @@ Extra objects on the JSON line:
                  batch run alone in a separate instrumented pass.
   cpu_baseline - the fp32 numpy oracle ("port") timed on this host on a bounded sample of the same workload.
   kernels      - per-family launches / ms of one instrumented step (all families).
+  rooflines    - one entry per family north_star asks evidence for: conv_gemm (fp32 MFMA TFLOP/s / 157.3),
+                 bigru_scan, dec_persistent and gl_iter (algorithmic GB/s / 8000), one batch run alone.
+  to_wav       - the same job through the 60-iteration Griffin-Lim (BASELINE.json configs[2], per GPU), timed with
+                 the same barrier / max-over-ranks protocol (`mel_linear` instead when --to-wav makes that the headline).
+  latency      - p50 wall time of one utterance (B=1) and of one batch alone, to mel+linear and to the waveform.
+  gpu_max_hw_queues, value_at_inherited_hw_queues - the hardware-queue setting the figure was taken at, and the
+                 headline leg repeated (child process) at the setting this process inherited.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 # More than three independent streams only overlap when the process may open more hardware queues than HIP's
 # default of 4 (measured: 4 streams 5.0M -> 6.2M frames/s with 8). Must be set before the HIP runtime loads.
-if int(os.environ.get('GPU_MAX_HW_QUEUES') or 0) < 8:
+# The inherited value is kept when --keep-hw-queues is given; both are recorded on the JSON line, and at N=1 the
+# headline leg is repeated in a child process at the inherited setting (`value_at_inherited_hw_queues`).
+HWQ_INHERITED = os.environ.get('GPU_MAX_HW_QUEUES')
+if '--keep-hw-queues' not in sys.argv and int(HWQ_INHERITED or 0) < 8:
     os.environ['GPU_MAX_HW_QUEUES'] = '8'
 
 import numpy as np
@@ -104,7 +115,7 @@ def cpu_baseline(hp, weights, T_in, S, budget_s=15.0):
     """fp32 numpy restatement (oracle/taco_oracle.py) on this host's cores: full hot path
     (encode -> decode -> post-net) on a bounded sample of the workload."""
     from oracle import taco_oracle as O
-    from tests.util import synth_ids
+    from tacotron_amd.data.synthetic import synth_ids
     try:
         from threadpoolctl import threadpool_info
         thr = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
@@ -143,6 +154,9 @@ def main():
     ap.add_argument('--decode-mode', type=int, default=2, help='0 eager per-stage kernels, 1 hipGraph, 2 persistent kernel')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the secondary legs (to-waveform rate, B=1 latencies, per-family rooflines, child run)')
+    ap.add_argument('--keep-hw-queues', action='store_true', help='do not raise GPU_MAX_HW_QUEUES to 8')
     args = ap.parse_args()
 
     import torch
@@ -150,7 +164,7 @@ def main():
     from tacotron_amd.engine import TacoEngine
     from tacotron_amd.hparams import HParams
     from tacotron_amd.weights import init_weights
-    from tests.util import synth_ids
+    from tacotron_amd.data.synthetic import synth_ids
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -191,10 +205,10 @@ def main():
     out = outs[0]
     counter = [0]
 
-    def step():
+    def step(to_wav):
         i = counter[0] % len(engines)
         counter[0] += 1
-        engines[i].synthesize(ids, lens, max_iters=S, to_wav=args.to_wav, out=outs[i])
+        engines[i].synthesize(ids, lens, max_iters=S, to_wav=to_wav, out=outs[i])
 
     def barrier():
         torch.cuda.synchronize()
@@ -202,17 +216,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def p50_latency(e, n_ids, n_lens, to_wav, o, reps):
+        """p50 wall time of one synthesis alone on the device (launch to synchronise), ms."""
+        lat = []
+        for _ in range(reps + 2):
+            t0 = time.perf_counter()
+            e.synthesize(n_ids, n_lens, max_iters=S, to_wav=to_wav, out=o)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        lat = sorted(lat[2:])                      # (two untimed: workspace growth, first-launch set-up)
+        return 1e3 * lat[len(lat) // 2]
+
+    def timed(n_steps, to_wav):
+        """n_steps passes over the batch, `streams` in flight, bracketed by barrier + synchronise; max over ranks."""
+        counter[0] = 0
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step(to_wav)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=eng.device if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     for _ in range(max(args.warmup, len(engines))):
-        step()
+        step(args.to_wav)
     barrier()
     # single-batch latency (one batch in flight), for the p50 figure
-    lat = []
-    for _ in range(5):
-        t0 = time.perf_counter()
-        eng.synthesize(ids, lens, max_iters=S, to_wav=args.to_wav, out=out)
-        torch.cuda.synchronize()
-        lat.append(time.perf_counter() - t0)
-    lat_ms = 1e3 * sorted(lat)[len(lat) // 2]
+    lat_ms = p50_latency(eng, ids, lens, args.to_wav, out, 5)
     # HIP event pairs around every launch of the decode-loop kernel, on each engine's own stream, over the timed
     # region itself (two event records per batch): the roofline's launch duration is measured live, under the
     # same contention as `value`
@@ -220,50 +254,72 @@ def main():
     if loop_fam and not args.no_roofline:
         for e in engines:
             e.timing_begin(loop_fam)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    el = time.perf_counter() - t0
+    el = timed(args.steps, args.to_wav)
     live_n, live_ms = 0, 0.0
     if loop_fam and not args.no_roofline:
         for e in engines:
             n_, ms_ = e.timing_end()
             live_n += n_
             live_ms += ms_
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=eng.device if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    # a persistent decode whose bounded wait ran out would have produced garbage at full speed: fail loudly
+    for e in engines:
+        e.decode_status()
     steps_run = int(out['steps'].item())
     frames_per_step = world * B * steps_run * hp.outputs_per_step
     value = frames_per_step * args.steps / el
+
+    def workload(to_wav):
+        return ('BASELINE.json configs[%d]%s: batched inference B=%d per GPU, %d-char inputs, fp32, max_iters=%d r=%d, '
+                'outputs mel+linear%s' % (2 if to_wav else 1, ' per GPU' if to_wav else '', B, T_in, S,
+                                          hp.outputs_per_step, ' + %d-iteration Griffin-Lim waveform' %
+                                          hp.griffin_lim_iters if to_wav else ''))
 
     res = {
         'metric': 'mel frames/sec (whole job)', 'value': value, 'unit': 'mel frames/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * el / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
         'data': 'synthetic (seeded character ids, random-init weights with TF default initialisers)',
-        'config': {'workload': 'BASELINE.json configs[1]: batched inference B=%d per GPU, %d-char inputs, fp32, '
-                               'max_iters=%d r=%d, outputs mel+linear%s' % (
-                                   B, T_in, S, hp.outputs_per_step,
-                                   ' + 60-iter Griffin-Lim wav' if args.to_wav else ''),
+        'config': {'workload': workload(args.to_wav),
                    'batch_per_gpu': B, 'global_batch': B * world, 'T_in': T_in, 'max_iters': S,
                    'frames_per_utterance': steps_run * hp.outputs_per_step, 'parallelism': 'utterance-sharded x%d' % world,
                    'streams_per_gpu': len(engines)},
         'p50_batch_latency_ms': lat_ms, 'batches_in_flight': len(engines),
+        'gpu_max_hw_queues': {'effective': os.environ.get('GPU_MAX_HW_QUEUES'), 'inherited': HWQ_INHERITED},
+        'decode_status': 'ok',
     }
+
+    # ---- secondary legs (BASELINE.json's metric also names the to-waveform rate and B=1 / batch p50 latencies)
+    if not args.no_extras:
+        other = not args.to_wav
+        n2 = max(12, min(args.steps, 60 if other else 200))
+        for _ in range(len(engines)):
+            step(other)                            # (workspace / output buffers of the other leg)
+        el2 = timed(n2, other)
+        for e in engines:
+            e.decode_status()
+        res['to_wav' if other else 'mel_linear'] = {
+            'value': frames_per_step * n2 / el2, 'unit': 'mel frames/s', 'ms_per_step': 1e3 * el2 / n2, 'steps': n2,
+            'workload': workload(other)}
+        if rank == 0:
+            o1 = {}
+            res['latency'] = {
+                'unit': 'ms, p50 of 9 (launch to synchronise, one synthesis alone on the GPU)',
+                'b1_mel_linear': p50_latency(eng, ids[:1], lens[:1], False, o1, 9),
+                'b1_to_wav': p50_latency(eng, ids[:1], lens[:1], True, o1, 9),
+                'batch_mel_linear': lat_ms if not args.to_wav else p50_latency(eng, ids, lens, False, out, 5),
+                'batch_to_wav': lat_ms if args.to_wav else p50_latency(eng, ids, lens, True, out, 5),
+                'batch': B}
 
     if rank == 0 and not args.no_roofline:
         work = family_work(hp, B, T_in, S)
         kinds = eng.kernel_kinds()
         fam = {}
+        inst_wav = args.to_wav or not args.no_extras      # the instrumented passes include the vocoder's families
 
         def one(k):
             # one batch alone on engine 0's stream, with HIP event pairs around every launch of family k
             eng.timing_begin(k)
-            eng.synthesize(ids, lens, max_iters=S, to_wav=args.to_wav, out=out)
+            eng.synthesize(ids, lens, max_iters=S, to_wav=inst_wav, out=out)
             n, ms = eng.timing_end()
             if n:
                 fam[k] = {'launches': n, 'ms': ms, 'avg_us': 1e3 * ms / n}
@@ -277,44 +333,77 @@ def main():
         if 'decode_graph' not in skip and args.decode_mode == 1:
             one('decode_graph')
         res['kernels'] = fam
-        leaf = {k: v for k, v in fam.items() if k != 'decode_graph'}
+        gl_fams = {'gl_mag', 'gl_iter', 'gl_ola'}
+        leaf = {k: v for k, v in fam.items() if k != 'decode_graph' and (args.to_wav or k not in gl_fams)}
         dom = max(leaf, key=lambda k: leaf[k]['ms'])
-        bound, amount = work[dom]
-        per_launch = amount / leaf[dom]['launches']
+
+        def roof(k, sec_per_launch, launches):
+            bound, amount = work[k]
+            per_launch = amount / launches
+            if bound == 'hbm':
+                ach, peak, unit = per_launch / sec_per_launch / 1e9, HBM_PEAK_GBS, 'GB/s'
+            else:
+                ach, peak, unit = per_launch / sec_per_launch / 1e12, FP32_MFMA_PEAK_TF, 'TFLOP/s'
+            return {'kernel': k, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit, 'frac': ach / peak,
+                    'launches_per_step': launches, 'avg_launch_us': 1e6 * sec_per_launch,
+                    'algorithmic_per_launch': per_launch}
+
         sec = leaf[dom]['ms'] * 1e-3 / leaf[dom]['launches']
         solo_us = 1e6 * sec
         if dom == loop_fam and live_n:
             sec = live_ms * 1e-3 / live_n          # average over the launches of the timed region
-        if bound == 'hbm':
-            ach, peak, unit = per_launch / sec / 1e9, HBM_PEAK_GBS, 'GB/s'
-        else:
-            ach, peak, unit = per_launch / sec / 1e12, FP32_MFMA_PEAK_TF, 'TFLOP/s'
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
             traffic = tj.get('B%d_Tin%d_S%d' % (B, T_in, S), {}).get(dom, {}).get('bytes_per_launch')
         except Exception:
             traffic = None
-        res['roofline'] = {'kernel': dom, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit,
-                           'frac': ach / peak, 'traffic': traffic, 'launches_per_step': leaf[dom]['launches'],
-                           'avg_launch_us': 1e6 * sec, 'avg_launch_us_one_batch_in_flight': solo_us,
-                           'launches_timed': live_n if dom == loop_fam and live_n else leaf[dom]['launches'],
-                           'algorithmic_per_launch': per_launch}
+        r0 = roof(dom, sec, leaf[dom]['launches'])
+        r0.update({'traffic': traffic, 'avg_launch_us_one_batch_in_flight': solo_us,
+                   'launches_timed': live_n if dom == loop_fam and live_n else leaf[dom]['launches']})
+        res['roofline'] = r0
+        # one entry per kernel family north_star asks evidence for (MFMA utilisation of the CBHG / post-net GEMMs,
+        # achieved GB/s of the decoder loop, the BiGRU scan and the vocoder): one batch alone, HIP events per launch
+        res['rooflines'] = [dict(roof(k, fam[k]['ms'] * 1e-3 / fam[k]['launches'], fam[k]['launches']),
+                                 measured='one batch alone, HIP event pair per launch')
+                            for k in ('conv_gemm', 'bigru_scan', 'dec_persistent', 'decode_graph', 'gl_iter')
+                            if k in fam and k in work]
         loop = 'dec_persistent' if 'dec_persistent' in fam else ('decode_graph' if 'decode_graph' in fam else None)
         if loop:
             b, amt = work[loop]
             s2 = fam[loop]['ms'] * 1e-3
             res['decode_loop'] = {'kernel': loop, 'ms': fam[loop]['ms'], 'us_per_decoder_step': 1e6 * s2 / S,
+                                  'us_per_decoder_step_live': (1e3 * live_ms / live_n / S) if live_n else None,
                                   'achieved_GBps': amt / s2 / 1e9, 'frac_of_hbm': amt / s2 / 1e9 / HBM_PEAK_GBS}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(hp, weights, T_in, S)
-    if rank == 0:
-        print(json.dumps(res))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     for e in engines:
         e.close()
+    if (rank == 0 and world == 1 and not args.no_extras and not args.keep_hw_queues and
+            os.environ.get('GPU_MAX_HW_QUEUES') != HWQ_INHERITED):
+        # the same headline leg at the hardware-queue count this process inherited (the GPU box exports 4)
+        env = dict(os.environ)
+        if HWQ_INHERITED is None:
+            env.pop('GPU_MAX_HW_QUEUES', None)
+        else:
+            env['GPU_MAX_HW_QUEUES'] = HWQ_INHERITED
+        cmd = [sys.executable, os.path.abspath(__file__), '--keep-hw-queues', '--no-extras', '--no-roofline',
+               '--no-cpu-baseline', '--steps', str(args.steps), '--warmup', str(args.warmup), '--batch', str(B),
+               '--t-in', str(T_in), '--max-iters', str(S), '--streams', str(len(engines)),
+               '--decode-mode', str(args.decode_mode)] + (['--to-wav'] if args.to_wav else [])
+        try:
+            cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+            line = [l for l in cp.stdout.splitlines() if l.startswith('{')][-1]
+            child = json.loads(line)
+            res['value_at_inherited_hw_queues'] = {'value': child['value'], 'ms_per_step': child['ms_per_step'],
+                                                   'gpu_max_hw_queues': HWQ_INHERITED}
+        except Exception as ex:                    # reported, never fatal for the headline line
+            res['value_at_inherited_hw_queues'] = {'error': repr(ex)[:200]}
+    if rank == 0:
+        print(json.dumps(res))
 
 
 if __name__ == '__main__':

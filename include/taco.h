@@ -70,6 +70,13 @@ typedef struct TacoHParams {
     float   power;                /* 1.5 */
     int32_t max_iters;            /* 200 */
     int32_t griffin_lim_iters;    /* 60 */
+    /* max-pool of the CBHG (hparams.py:31-32,41-42 -> model/modules.py:70-71). The kernels implement the
+     * reference's values only (width 2, stride 1, fused into proj_1's operand loader); taco_create rejects
+     * anything else instead of silently computing a different graph. */
+    int32_t encoder_pooling_width;  /* 2 */
+    int32_t encoder_pooling_stride; /* 1 */
+    int32_t decoder_pooling_width;  /* 2 */
+    int32_t decoder_pooling_stride; /* 1 */
 } TacoHParams;
 
 /* One TF variable of the inference graph: name relative to `model/inference/`
@@ -183,8 +190,18 @@ int32_t taco_num_kernel_kinds(void);
 int taco_set_decode_graph(taco_handle h, int32_t mode);
 
 /* Synchronous check of the last persistent decode (reads a few device words; call after the stream has been
- * synchronised): <0 if one of its bounded inter-workgroup waits timed out, in which case its outputs are invalid. */
+ * synchronised): <0 if one of its bounded inter-workgroup waits timed out, in which case its outputs are invalid.
+ * Failure handling of the persistent mode (no reference counterpart; the reference's loop is a tf.while_loop inside
+ * session.run, synthesizer.py:39-43): a launch whose wait runs out sets a sticky word of the handle, so persistent
+ * launches of that handle that are already queued return at once (one time-out, not one per queued launch); the next
+ * taco_decode / taco_synthesize that finds the previous launch aborted (from a pinned host mirror, no synchronisation)
+ * returns <0 with this message - the PREVIOUS call's outputs were invalid - and the handle runs mode 1 from then on,
+ * until taco_set_decode_graph(h, 2) re-arms it. A batch with more workgroups than the device has CUs runs mode 1. */
 int taco_decode_status(taco_handle h);
+
+/* Test hook (no reference counterpart): sets the handle's sticky abort word as a timed-out persistent decode would,
+ * so the failure path above can be exercised without hanging a GPU. */
+int taco_debug_poison_decoder(taco_handle h);
 
 /* Test hook (no reference counterpart): one launch of the dense / SAME-conv1d implicit-GEMM
  * kernel, C[m,n] = (act(sum_{j,c} X[b,t+j-padl,c] W[j*Cin+c,n] + bias[n])) * scale[n] + shift[n]

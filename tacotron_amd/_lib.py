@@ -21,7 +21,9 @@ _HP_FIELDS = [
 class TacoHParams(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_int32) for n in _HP_FIELDS] +
                 [('min_level_db', ctypes.c_float), ('ref_level_db', ctypes.c_float), ('power', ctypes.c_float),
-                 ('max_iters', ctypes.c_int32), ('griffin_lim_iters', ctypes.c_int32)])
+                 ('max_iters', ctypes.c_int32), ('griffin_lim_iters', ctypes.c_int32),
+                 ('encoder_pooling_width', ctypes.c_int32), ('encoder_pooling_stride', ctypes.c_int32),
+                 ('decoder_pooling_width', ctypes.c_int32), ('decoder_pooling_stride', ctypes.c_int32)])
 
 
 class TacoWeightEntry(ctypes.Structure):
@@ -31,7 +33,8 @@ class TacoWeightEntry(ctypes.Structure):
 
 EXPORTS = ['taco_last_error', 'taco_create', 'taco_destroy', 'taco_workspace_bytes', 'taco_encode',
            'taco_decode', 'taco_decode_teacher', 'taco_postnet', 'taco_griffin_lim', 'taco_griffin_lim_librosa', 'taco_spectrogram', 'taco_spectrogram_workspace_bytes', 'taco_synthesize', 'taco_timing_begin',
-           'taco_timing_end', 'taco_kernel_name', 'taco_num_kernel_kinds', 'taco_set_decode_graph', 'taco_decode_status', 'taco_debug_conv_gemm']
+           'taco_timing_end', 'taco_kernel_name', 'taco_num_kernel_kinds', 'taco_set_decode_graph', 'taco_decode_status', 'taco_debug_conv_gemm',
+           'taco_debug_poison_decoder']
 
 _lib = None
 
@@ -87,6 +90,8 @@ def load_library():
     lib.taco_decode_teacher.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.taco_decode_status.restype = ctypes.c_int
     lib.taco_decode_status.argtypes = [vp]
+    lib.taco_debug_poison_decoder.restype = ctypes.c_int
+    lib.taco_debug_poison_decoder.argtypes = [vp]
     lib.taco_debug_conv_gemm.restype = ctypes.c_int
     lib.taco_debug_conv_gemm.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp]
     _lib = lib
@@ -129,4 +134,7 @@ def make_hparams_struct(hp):
     s.power = hp.power
     s.max_iters = hp.max_iters
     s.griffin_lim_iters = hp.griffin_lim_iters
+    # carried so that taco_create can refuse values the kernels do not implement (modules.py:70-71)
+    s.encoder_pooling_width, s.encoder_pooling_stride = hp.encoder_pooling_width, hp.encoder_pooling_stride
+    s.decoder_pooling_width, s.decoder_pooling_stride = hp.decoder_pooling_width, hp.decoder_pooling_stride
     return s

@@ -109,6 +109,14 @@ struct taco_ctx {
     int decode_mode = 2;           // 0 eager per-stage kernels, 1 captured hipGraph of them, 2 persistent kernel
     unsigned long long* sync_words = nullptr;  // persistent decoder: per 16-utterance group {counter, abort}, 128 B apart
     int last_sync_groups = 0;                  // groups used by the last decode if it was persistent, else 0
+    int last_persist_wgs = 0;                  // its grid size (for the status message)
+    // Host mirror of the status words: a 32-byte device-to-host copy into pinned memory follows every persistent
+    // launch on its stream, so the next taco_decode of the handle learns without a synchronisation whether the
+    // previous launch aborted. persist_broken: it did; the handle uses the captured per-stage path from then on.
+    unsigned* host_status = nullptr;
+    hipEvent_t status_ev = nullptr;
+    bool status_pending = false;
+    bool persist_broken = false;
     unsigned long long* dbg_stamps = nullptr;  // PD_STAMPS builds: 64 s_memrealtime stamps of one step
     std::vector<GraphEntry> graphs;
 };
@@ -528,6 +536,11 @@ extern "C" int taco_create(const TacoHParams* hp, const TacoWeightEntry* weights
     if (p.n_fft != 2048 || p.num_freq != 1025 || p.win_length > 2048 || p.win_length < 2 || (p.win_length & 1) ||
         (p.hop_length & 1) || p.hop_length < 2 || p.hop_length > p.win_length)
         return fail("taco_create: Griffin-Lim kernel needs n_fft=2048, num_freq=1025, even hop <= even win <= 2048");
+    if (p.encoder_pooling_width != 2 || p.encoder_pooling_stride != 1 || p.decoder_pooling_width != 2 ||
+        p.decoder_pooling_stride != 1)
+        return fail("taco_create: only the reference's max-pool (pooling_width 2, pooling_stride 1; hparams.py:31-32,"
+                    "41-42) is implemented, got encoder %d/%d decoder %d/%d", p.encoder_pooling_width,
+                    p.encoder_pooling_stride, p.decoder_pooling_width, p.decoder_pooling_stride);
     if (p.encoder_K < 1 || p.decoder_K < 1 || p.outputs_per_step < 1 || p.num_chars < 1 || p.encoder_highways < 0 ||
         p.decoder_highways < 0)
         return fail("taco_create: bad hparams");
@@ -650,6 +663,12 @@ extern "C" int taco_create(const TacoHParams* hp, const TacoWeightEntry* weights
         c->window = L.upload(win);
         c->sync_words = reinterpret_cast<unsigned long long*>(L.upload(std::vector<float>(8 * 32, 0.f)));
         ok = c->twiddle && c->window && c->sync_words;
+        if (ok && (hipHostMalloc(reinterpret_cast<void**>(&c->host_status), 64, hipHostMallocDefault) != hipSuccess ||
+                   hipEventCreateWithFlags(&c->status_ev, hipEventDisableTiming) != hipSuccess)) {
+            L.err = "cannot allocate the decoder status mirror";
+            ok = false;
+        }
+        if (ok) memset(c->host_status, 0, 64);
     }
     if (ok) {
         // encoder prenet of every symbol, once: prenet(embedding[id]) is a pure function of the id
@@ -689,6 +708,8 @@ extern "C" void taco_destroy(taco_handle h) {
         if (g.graph) (void)hipGraphDestroy(g.graph);
     }
     for (hipEvent_t e : h->timing.ev) (void)hipEventDestroy(e);
+    if (h->status_ev) (void)hipEventDestroy(h->status_ev);
+    if (h->host_status) (void)hipHostFree(h->host_status);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
 }
@@ -836,6 +857,28 @@ void persist_launched(int device, int wgs, hipStream_t s) {
 }
 }  // namespace
 
+// Text for a set of status words (PD_SYNC_*) whose abort flag is set.
+static int persist_fail(const unsigned* w, int wgs) {
+    if (w[PD_SYNC_ABORT] == 2u)
+        return fail("persistent decoder: the launch returned at once because an earlier persistent decode of this handle "
+                    "had timed out; its outputs are invalid (taco_set_decode_graph(h, 2) re-arms the handle)");
+    return fail("persistent decoder: a bounded inter-workgroup wait timed out; outputs are invalid "
+                "(first: workgroup %u waiting for step %u stage %u; %u of %d workgroups had started%s)",
+                w[PD_SYNC_WG], (w[PD_SYNC_TAG] - 1) / 13, (w[PD_SYNC_TAG] - 1) % 13, w[PD_SYNC_ARRIVED], wgs,
+                (int)w[PD_SYNC_ARRIVED] < wgs ? ": the device could not hold all of them at once" : "");
+}
+
+// Looks at the pinned mirror of the previous persistent launch's status words if that launch has completed (no
+// synchronisation). Returns -1 (message set) when it aborted: its outputs were invalid, and the handle leaves
+// persistent mode.
+static int persist_check_previous(taco_ctx* c) {
+    if (!c->status_pending || hipEventQuery(c->status_ev) != hipSuccess) return 0;
+    c->status_pending = false;
+    if (c->host_status[PD_SYNC_ABORT] == 0u) return 0;
+    c->persist_broken = true;
+    return persist_fail(c->host_status, c->last_persist_wgs);
+}
+
 static int decode_impl(taco_ctx* c, const float* enc_out, int B, int T_in, int S, const float* keep, float* mel,
                        float* align, int32_t* steps_run, Carver& ws, hipStream_t s, const float* teacher = nullptr) {
     const TacoHParams& hp = c->hp;
@@ -893,8 +936,17 @@ static int decode_impl(taco_ctx* c, const float* enc_out, int B, int T_in, int S
     const size_t pe_floats = (((size_t)B * T_in * 2) + 63) & ~(size_t)63;
     // granule buffers of dec_persistent.hip: [h_att;ctx] x2, h1 x2, h2 x2, p1, p2, rh x3, u x3, q, d0, o1, o2
     const size_t pregion_floats = (size_t)PD_REGION_DIMS * g1 + pe_floats + (size_t)S * 400 * g1;
-    if (c->decode_mode == 2 && default_sizes && !keep && !teacher && !fine_timing && Bp / 16 <= 8 &&
-        pregion_floats * 4 < (size_t)1 << 31) {
+    // a caller that is capturing `s` into a graph of its own gets no host-side status plumbing (event queries and
+    // the device-to-host copy stay out of its graph); taco_decode_status still works after a synchronisation
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = s != nullptr && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    if (!capturing && persist_check_previous(c)) return -1;     // the PREVIOUS decode's outputs were invalid
+    int dev_cus = 0;
+    if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || dev_cus <= 0)
+        dev_cus = 256;
+    // (a launch that cannot be resident as a whole - more workgroups than CUs - takes the per-stage path instead)
+    if (c->decode_mode == 2 && !c->persist_broken && default_sizes && !keep && !teacher && !fine_timing && Bp / 16 <= 8 &&
+        32 * (Bp / 16) <= dev_cus && pregion_floats * 4 < (size_t)1 << 31) {
         float* pregion = ws.take<float>(pregion_floats + 1024);   // + 4 KB tail for diagnostic stamps (PD_STAMPS builds)
         if (!ws.ok()) return fail("taco_decode: workspace too small");
         GemmArgs g{enc_out, Dv, B * T_in, T_in, c->mem_layer.Cin, 1, 0, c->mem_layer.W, c->mem_layer.ldw,
@@ -926,6 +978,12 @@ static int decode_impl(taco_ctx* c, const float* enc_out, int B, int T_in, int S
         if (launch_dec_persistent(a, s, tm)) return fail("taco_decode: cannot configure the persistent decoder");
         persist_launched(c->device, wgs, s);
         c->last_sync_groups = 1;
+        c->last_persist_wgs = wgs;
+        if (!capturing) {
+            HIP_OK(hipMemcpyAsync(c->host_status, sync, 32, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipEventRecord(c->status_ev, s));
+            c->status_pending = true;
+        }
         launch_dec_finalize(pregion + a.o_outQ, 1, d.alignS, d.nz, S, NR, B, Bp, T_in, mel, align, steps_run, s, tm);
         return 0;
     }
@@ -1192,6 +1250,14 @@ extern "C" int32_t taco_num_kernel_kinds(void) { return KK_COUNT; }
 extern "C" int taco_set_decode_graph(taco_handle h, int32_t mode) {
     if (!h) return fail("taco_set_decode_graph: null handle");
     if (mode < 0 || mode > 2) return fail("taco_set_decode_graph: mode must be 0, 1 or 2");
+    if (mode == 2 && h->persist_broken) {
+        // explicit re-arm after a timed-out persistent decode: wait for the handle's work, clear the sticky word
+        HIP_OK(hipSetDevice(h->device));
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipMemset(reinterpret_cast<unsigned*>(h->sync_words) + PD_SYNC_STICKY, 0, 16));
+        h->persist_broken = false;
+        h->status_pending = false;
+    }
     h->decode_mode = mode;
     return 0;
 }
@@ -1200,10 +1266,9 @@ extern "C" int taco_decode_status(taco_handle h) {
     if (!h) return fail("taco_decode_status: null handle");
     if (!h->last_sync_groups) return 0;
     HIP_OK(hipSetDevice(h->device));
-    unsigned long long w = 0;
-    unsigned info[4] = {0, 0, 0, 0};
-    HIP_OK(hipMemcpy(info, h->sync_words, 16, hipMemcpyDeviceToHost));
-    w = (unsigned long long)info[1] << 32;
+    unsigned info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_OK(hipMemcpy(info, h->sync_words, 32, hipMemcpyDeviceToHost));
+    h->status_pending = false;                 // (this read supersedes the asynchronous mirror)
 #ifdef PD_PHASE_STAMPS
     {
         unsigned long long st[3];
@@ -1223,9 +1288,18 @@ extern "C" int taco_decode_status(taco_handle h) {
         fprintf(stderr, "\n");
     }
 #endif
-    if (w >> 32)
-        return fail("persistent decoder: a bounded inter-workgroup wait timed out; outputs are invalid "
-                    "(first: workgroup %u waiting for step %u stage %u)", info[2], (info[3] - 1) / 13, (info[3] - 1) % 13);
+    if (info[PD_SYNC_ABORT] != 0u) {
+        h->persist_broken = true;
+        return persist_fail(info, h->last_persist_wgs);
+    }
+    return 0;
+}
+
+extern "C" int taco_debug_poison_decoder(taco_handle h) {
+    if (!h) return fail("taco_debug_poison_decoder: null handle");
+    HIP_OK(hipSetDevice(h->device));
+    const unsigned one = 1u;
+    HIP_OK(hipMemcpy(reinterpret_cast<unsigned*>(h->sync_words) + PD_SYNC_STICKY, &one, 4, hipMemcpyHostToDevice));
     return 0;
 }
 

@@ -114,6 +114,10 @@ struct Spin {
                 if (__hip_atomic_exchange(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                     __hip_atomic_store(abort_word + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(abort_word + 2, where, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // sticky word of the handle (PD_SYNC_STICKY, not cleared per launch): launches of this handle that
+                    // are already queued behind this one leave at once instead of running into the same wait
+                    __hip_atomic_store(abort_word + (PD_SYNC_STICKY - PD_SYNC_ABORT), 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
                 }
                 dead = true;
             }
@@ -293,11 +297,32 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
 #ifdef PD_PHASE_STAMPS   // diagnostic build: when did workgroup 0 start, finish step 0 (everybody resident), finish
     if (blockIdx.x == 0 && tid == 0) reinterpret_cast<unsigned long long*>(a.sync)[8] = __builtin_amdgcn_s_memrealtime();
 #endif
+    {
+        // census of the launch (how many workgroups ever started: names an over-subscribed device in
+        // taco_decode_status) and the handle's sticky abort word: set by a launch whose bounded wait ran out, it
+        // makes every later persistent launch of the handle return before it waits for anything
+        unsigned* sw = reinterpret_cast<unsigned*>(a.sync);
+        unsigned* flag_s = reinterpret_cast<unsigned*>(smem);       // (one decision per workgroup)
+        if (tid == 0) {
+            __hip_atomic_fetch_add(sw + PD_SYNC_ARRIVED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned sticky = __hip_atomic_load(sw + PD_SYNC_STICKY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sticky != 0u &&
+                __hip_atomic_exchange(sw + PD_SYNC_ABORT, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                __hip_atomic_store(sw + PD_SYNC_WG, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sw + PD_SYNC_TAG, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            *flag_s = sticky;
+        }
+        __syncthreads();
+        const unsigned leave = *flag_s;
+        __syncthreads();                                            // smem is `red` from here on
+        if (leave != 0u) return;
+    }
     const int b0 = bt * 16, Bpad = a.Bpad;
     const int lb = b0 + (lane & 15), lq = lane >> 4;
     const bool col_on = lb < a.B;            // this lane's batch column is a real utterance
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.region, 0, a.region_bytes, 0x00020000);
-    Spin spin{reinterpret_cast<unsigned*>(a.sync) + 1, 0u, false, 0u, 0ull};
+    Spin spin{reinterpret_cast<unsigned*>(a.sync) + PD_SYNC_ABORT, 0u, false, 0u, 0ull};
 #ifdef PD_STAMPS
     spin.st_lds = reinterpret_cast<unsigned long long*>(smem + 4096); spin.stamp_i = 0; spin.stamp_on = false;
 #endif

@@ -135,12 +135,17 @@ struct DecPersistArgs {
     unsigned region_bytes;
     unsigned o_hc, o_h1, o_h2, o_p1, o_p2, o_rh, o_u, o_q, o_d0, o_o1, o_o2, o_e, o_outQ;   // o_hc: 2 x [h_att ; ctx]
     float* alignS;            // [S][B][T_in]
-    unsigned long long* sync; // {unused, abort word}, zeroed per call
+    unsigned long long* sync; // handle-owned status words (PD_SYNC_* below); the first 128 bytes are zeroed per call
     int B, Bpad, T_in, S;
     int lds_keys, lds_vals;   // filled by the launcher: key rows per attention part staged in LDS, values staged or not
     unsigned long long* dbg;  // diagnostic builds (-DPD_STAMPS): s_memrealtime stamps of workgroup 0, step 5
 };
 int launch_dec_persistent(DecPersistArgs a, hipStream_t s, Timing* tm);
+// Status words of a handle's persistent decodes, as unsigned indices into DecPersistArgs::sync. [0, 32) are per launch
+// (zeroed by the launcher): abort flag (1 = a bounded wait ran out, 2 = the launch left at once because the handle's
+// sticky word was set), then the workgroup and the tag of the first such wait, and the count of workgroups that
+// started. PD_SYNC_STICKY lies beyond the per-launch block: set with the abort flag, cleared only by taco_set_decode_graph.
+enum : int { PD_SYNC_ABORT = 1, PD_SYNC_WG = 2, PD_SYNC_TAG = 3, PD_SYNC_ARRIVED = 4, PD_SYNC_STICKY = 32 };
 
 // Griffin-Lim
 struct GLPlan {

@@ -34,12 +34,30 @@ def test_hparams_struct_matches_header():
     from tacotron_amd import _lib
     from tacotron_amd.hparams import HParams
     s = _lib.make_hparams_struct(HParams())
-    assert ctypes.sizeof(s) == 33 * 4
+    assert ctypes.sizeof(s) == 37 * 4
     assert (s.num_chars, s.prenet_depth2, s.encoder_K, s.decoder_proj2, s.hop_length, s.win_length) == (95, 128, 16, 80, 300, 1200)
     hdr = open(os.path.join(ROOT, 'include', 'taco.h')).read()
     body = hdr[hdr.index('typedef struct TacoHParams {'):hdr.index('} TacoHParams;')]
     fields = re.findall(r'^\s*(?:int32_t|float)\s+(\w+);', body, flags=re.M)
     assert fields == [f[0] for f in _lib.TacoHParams._fields_]
+
+
+def test_create_rejects_non_default_pooling():
+    """hparams.py:31-32,41-42 -> modules.py:70-71: only pooling width 2 / stride 1 is implemented (fused into proj_1's
+    operand loader); any other value is refused at taco_create (before any device call) instead of silently computing
+    a different graph."""
+    import ctypes
+    from tacotron_amd import _lib
+    from tacotron_amd.hparams import HParams
+    lib = _lib.load_library()
+    for name in ('encoder_pooling_width', 'encoder_pooling_stride', 'decoder_pooling_width', 'decoder_pooling_stride'):
+        hp = HParams()
+        hp.set_hparam(name, 3)
+        s = _lib.make_hparams_struct(hp)
+        entries = (_lib.TacoWeightEntry * 1)()
+        h = ctypes.c_void_p()
+        assert lib.taco_create(ctypes.byref(s), entries, 0, 0, ctypes.byref(h)) < 0
+        assert 'max-pool' in _lib.last_error() and not h.value
 
 
 def test_no_cpu_fallback():

@@ -386,3 +386,87 @@ def test_process_utterance_writes_reference_format(tmp_path, hp):
     w = audio.load_wav(wav_path).astype(np.float64)
     assert np.abs(spec.T - O.spectrogram_librosa(w, hp)).max() < 2e-3
     assert np.abs(mel.T - O.mel_spectrogram_librosa(w, hp)).max() < 2e-3
+
+
+def test_persistent_abort_costs_one_timeout_then_mode1(hp, weights):
+    """Failure path of the persistent decoder (include/taco.h, taco_decode_status): a launch whose bounded wait ran
+    out sets the handle's sticky word; launches queued behind it return at once (not one time-out each), the next
+    taco_decode refuses once (the previous outputs were invalid), later calls run the per-stage path and are correct,
+    and a mode-1 decode never reports the stale status of an earlier persistent launch (the case of round 1's t5.log).
+    The time-out itself is simulated with taco_debug_poison_decoder: no GPU is hung for this test."""
+    import time
+    import torch
+    from tacotron_amd.engine import TacoEngine, TacoError
+    eng = TacoEngine(weights, hp)
+    try:
+        rng = np.random.default_rng(21)
+        enc = (0.5 * rng.standard_normal((3, 20, 256))).astype(np.float32)
+        S = 6
+        ref_mel, ref_al, _ = O.decode(enc.astype(np.float64), weights, hp, max_iters=S)
+        m0, a0, _ = eng.decode(enc, max_iters=S)
+        torch.cuda.synchronize()
+        eng.decode_status()
+        assert rel_l1(_np(m0), ref_mel) < 1e-3
+        m0 = _np(m0).copy()
+        # ---- path A: nobody asks for the status; the next decode call finds out by itself
+        assert eng.lib.taco_debug_poison_decoder(eng.handle) == 0
+        t0 = time.perf_counter()
+        refused = False
+        for _ in range(3):                       # queued persistent launches: each must leave at once
+            try:
+                eng.decode(enc, max_iters=S)
+            except TacoError as ex:              # (the host may already have seen the first one's abort)
+                assert 'persistent decoder' in str(ex)
+                refused = True
+                break
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 5.0    # one wait is bounded at 10 s; three time-outs would be 30 s
+        if not refused:                          # the first call after the aborted launch completed refuses, once
+            with pytest.raises(TacoError, match='persistent decoder'):
+                eng.decode(enc, max_iters=S)
+        m1, a1, _ = eng.decode(enc, max_iters=S)             # per-stage path from now on
+        torch.cuda.synchronize()
+        eng.decode_status()                                   # no stale status from the aborted launches
+        assert rel_l1(_np(m1), ref_mel) < 1e-3 and rel_l1(_np(a1), ref_al) < 1e-3
+        assert np.abs(_np(m1) - m0).max() < 1e-4
+        # ---- re-arm: persistent mode again, bit-identical to the first run
+        eng.set_decode_graph(2)
+        m2, _, _ = eng.decode(enc, max_iters=S)
+        torch.cuda.synchronize()
+        eng.decode_status()
+        assert np.array_equal(_np(m2), m0)
+        # ---- path B: the caller asks (engine.finish does): decode_status reports, the handle falls back
+        assert eng.lib.taco_debug_poison_decoder(eng.handle) == 0
+        eng.decode(enc, max_iters=S)
+        torch.cuda.synchronize()
+        with pytest.raises(TacoError, match='persistent decoder'):
+            eng.decode_status()
+        m3, _, _ = eng.decode(enc, max_iters=S)
+        torch.cuda.synchronize()
+        eng.decode_status()
+        assert np.array_equal(_np(m3), _np(m1))
+    finally:
+        eng.close()
+
+
+def test_cfg3_full_size_to_waveform(engine, hp):
+    """configs[2] per GPU (a shard of 32 of the 256 utterances): B=32, T_in=150, 200 decoder steps, all 60
+    Griffin-Lim iterations, end to end to the waveform in one taco_synthesize (synthesizer.py:26,39-45 run for a
+    batch). Full-size properties: shapes, finiteness, utterance 0 bit-identical to the same utterance run alone
+    (shard invariance through the vocoder); and the waveform of that utterance against the fp64 oracle's
+    Griffin-Lim of the same linear spectrogram."""
+    import torch
+    ids, lens = synth_ids(np.random.default_rng(0), 32, 150, ragged=False)
+    o = engine.finish(engine.synthesize(ids, lens, to_wav=True), to_wav=True)
+    assert o['steps_run'] == 200
+    wav, lin = o['wav'], o['linear']
+    assert tuple(wav.shape) == (32, 999 * 300 + 1200) and tuple(lin.shape) == (32, 1000, 1025)
+    assert bool(torch.isfinite(wav).all()) and float(wav.abs().max()) > 0
+    wav0, lin0 = wav[0].clone(), _np(lin[0]).copy()
+    o1 = engine.finish(engine.synthesize(ids[:1], lens[:1], to_wav=True), to_wav=True)
+    assert np.array_equal(_np(o1['linear'][0]), lin0)
+    assert torch.equal(o1['wav'][0], wav0)
+    ref = O.spectrogram_tensorflow_inv(lin0.astype(np.float64), hp)
+    err = float(np.linalg.norm(_np(wav0) - ref) / np.linalg.norm(ref))
+    print('cfg3: wav of utterance 0 vs oracle Griffin-Lim, relL2 %.2e' % err)
+    assert err < 1e-3

@@ -11,7 +11,7 @@ import numpy as np, torch
 from tacotron_amd.engine import TacoEngine
 from tacotron_amd.hparams import HParams
 from tacotron_amd.weights import init_weights
-from tests.util import synth_ids
+from tacotron_amd.data.synthetic import synth_ids
 n_eng = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 hp = HParams(); w = init_weights(hp, seed=1234)

@@ -8,7 +8,7 @@ import numpy as np, torch
 from tacotron_amd.engine import TacoEngine
 from tacotron_amd.hparams import HParams
 from tacotron_amd.weights import init_weights
-from tests.util import synth_ids
+from tacotron_amd.data.synthetic import synth_ids
 hp = HParams()
 eng = TacoEngine(init_weights(hp, seed=1234), hp)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32

@@ -5,7 +5,7 @@ import numpy as np, torch
 from tacotron_amd.engine import TacoEngine
 from tacotron_amd.hparams import HParams
 from tacotron_amd.weights import init_weights
-from tests.util import synth_ids
+from tacotron_amd.data.synthetic import synth_ids
 
 hp = HParams()
 eng = TacoEngine(init_weights(hp, seed=1234), hp)
