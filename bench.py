@@ -394,6 +394,7 @@ def main():
                '--no-cpu-baseline', '--steps', str(args.steps), '--warmup', str(args.warmup), '--batch', str(B),
                '--t-in', str(T_in), '--max-iters', str(S), '--streams', str(len(engines)),
                '--decode-mode', str(args.decode_mode)] + (['--to-wav'] if args.to_wav else [])
+        cp = None
         try:
             cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
             line = [l for l in cp.stdout.splitlines() if l.startswith('{')][-1]
@@ -401,7 +402,8 @@ def main():
             res['value_at_inherited_hw_queues'] = {'value': child['value'], 'ms_per_step': child['ms_per_step'],
                                                    'gpu_max_hw_queues': HWQ_INHERITED}
         except Exception as ex:                    # reported, never fatal for the headline line
-            res['value_at_inherited_hw_queues'] = {'error': repr(ex)[:200]}
+            res['value_at_inherited_hw_queues'] = {'error': repr(ex)[:200],
+                                                   'stderr_tail': (cp.stderr[-400:] if cp is not None else None)}
     if rank == 0:
         print(json.dumps(res))
 

@@ -5,6 +5,7 @@ save side of model/tacotron.py:133,169) for the variables of the inference graph
 `<prefix>.index` + `<prefix>.data-0000N-of-0000M` as TF 1.15 writes them (format: SURVEY.md Appendix B, restated
 from the published TF / LevelDB sources; TF itself is not installed here and the reference ships no checkpoint,
 so this module is checked against its own writer only - "parity unpinned", tests/test_cpu_tf_checkpoint.py).
+Variables are matched to the graph by pattern and shape (match_variables), tensor CRCs are verified by default.
 
   index file  = LevelDB-style immutable table: data blocks of prefix-compressed entries
                 (varint shared, varint non_shared, varint value_len, key suffix, value) + restart array + count,
@@ -17,6 +18,7 @@ so this module is checked against its own writer only - "parity unpinned", tests
   data files  = raw little-endian row-major tensor bytes at [offset, offset + size).
 """
 import os
+import re
 import struct
 
 import numpy as np
@@ -47,11 +49,39 @@ def _crc_table():
     return _CRC_TABLE
 
 
-def crc32c(data, crc=0):
+def _crc_scalar(c, data):
+    """Raw register update (no pre/post inversion) over `data`, one byte at a time."""
     t = _crc_table()
-    c = crc ^ 0xFFFFFFFF
-    for b in bytes(data):
+    for b in data:
         c = t[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c
+
+
+def crc32c(data, crc=0):
+    """CRC-32C of `data` (continuing from `crc`). Large inputs are cut into equal chunks whose registers advance in
+    lock-step as one numpy vector (a table lookup per byte position for all chunks at once); the chunk results are
+    then chained with the CRC's linearity: state(c, d) = advance_len(d)(c) ^ state(0, d)."""
+    data = bytes(data)
+    n = len(data)
+    c = crc ^ 0xFFFFFFFF
+    if n < 1 << 14:
+        return _crc_scalar(c, data) ^ 0xFFFFFFFF
+    lanes = min(1 << 16, n // 64)
+    L = n // lanes
+    head = n - lanes * L
+    c = _crc_scalar(c, data[:head])
+    t = np.asarray(_crc_table(), np.uint32)
+    body = np.frombuffer(data, np.uint8, count=lanes * L, offset=head).reshape(lanes, L)
+    st = np.zeros(lanes, np.uint32)
+    # Z[k][v]: the register (v << 8k) advanced over L zero bytes
+    z = (np.arange(256, dtype=np.uint32)[None, :] << (8 * np.arange(4, dtype=np.uint32))[:, None]).reshape(-1)
+    for j in range(L):
+        st = t[(st ^ body[:, j]) & 0xFF] ^ (st >> 8)
+        z = t[z & 0xFF] ^ (z >> 8)
+    z = z.reshape(4, 256).tolist()
+    z0, z1, z2, z3 = z
+    for s_i in st.tolist():
+        c = z0[c & 0xFF] ^ z1[(c >> 8) & 0xFF] ^ z2[(c >> 16) & 0xFF] ^ z3[c >> 24] ^ s_i
     return c ^ 0xFFFFFFFF
 
 
@@ -193,9 +223,10 @@ def read_index(prefix, verify=True):
     return entries, header
 
 
-def read_checkpoint(prefix, names=None, verify_crc=False):
-    """{name: ndarray} of the bundle's tensors (all, or only `names`). verify_crc also checks every tensor's
-    CRC32C (pure Python: slow for large tensors; the index blocks are always checked)."""
+def read_checkpoint(prefix, names=None, verify_crc=True):
+    """{name: ndarray} of the bundle's tensors (all, or only `names`). verify_crc (default) checks every tensor's
+    CRC32C against its index entry (vectorised, ~0.2 s for the 28 MB of a Tacotron checkpoint); the index blocks are
+    always checked."""
     entries, header = read_index(prefix)
     out, files = {}, {}
     try:
@@ -298,35 +329,133 @@ def write_checkpoint(prefix, tensors, block_bytes=4096):
 GRAPH_PREFIX = 'model/inference/'      # scopes of synthesizer.py:23 and model/tacotron.py:31
 
 
-def load_tacotron_weights(prefix, hp=None, verify_crc=False):
-    """The inference-graph variables of a checkpoint the reference saved (model/tacotron.py:169), as the
-    {name relative to model/inference/: float32 array} dict the engine takes. Optimiser slots (`.../Adam`,
-    `.../Adam_1`, `model/optimizer/...`) and `global_step` are skipped; anything else that does not fit the graph is
-    reported by name and shape."""
-    from .weights import check_weights, variable_specs
-    want = {n for n, _, _ in variable_specs(hp)}
-    entries, _ = read_index(prefix)
-    pick, ignored, strange = {}, [], []
-    for name in entries:
+_BN_RE = re.compile(r'^(.*?)batch_normalization(?:_(\d+))?/(gamma|beta|moving_mean|moving_variance)$')
+# scope segments some TF 1.x releases insert and others do not (`cell_{1,2}/[residual_wrapper/]
+# gru_cell/...`, model/decoder.py:28-32): dropped from both sides before names are compared
+_OPTIONAL_SEGMENTS = ('residual_wrapper/',)
+
+
+def _canonical(rel):
+    for seg in _OPTIONAL_SEGMENTS:
+        rel = rel.replace(seg, '')
+    return rel
+
+
+def match_variables(entries, hp=None):
+    """Match the variables of a checkpoint index ({full name: {'shape': ...}}) to the inference graph's variables by
+    pattern and shape, not by exact string:
+      * names are taken relative to `model/inference/`; optimiser slots (`.../Adam`, `.../Adam_1`), `global_step` and
+        everything outside that scope are ignored;
+      * optional scope segments (`residual_wrapper/`) may be present or absent;
+      * batch-norm scopes are matched by ORDER inside their enclosing scope: `tf.layers.batch_normalization` is called
+        outside the conv's own scope (model/modules.py:138-140), so TF auto-numbers it (`batch_normalization`,
+        `_1`, ...), per enclosing scope in TF 1.15 but graph-wide under other naming rules; the k-th expected BN of a
+        scope takes the k-th present one, sorted by its number;
+      * a shape mismatch is never papered over.
+    Returns (mapping {graph name: checkpoint name}, problems [str], leftovers [checkpoint names under the scope that
+    nothing claimed])."""
+    from .weights import variable_specs
+    specs = variable_specs(hp)
+    cand, bn_have = {}, {}
+    inside = []
+    for name, e in entries.items():
         if not name.startswith(GRAPH_PREFIX):
-            ignored.append(name)
             continue
         rel = name[len(GRAPH_PREFIX):]
-        if rel in want:
-            pick[name] = rel
-        elif rel.endswith('/Adam') or rel.endswith('/Adam_1') or rel == 'global_step':
-            ignored.append(name)
+        if rel.endswith('/Adam') or rel.endswith('/Adam_1') or rel == 'global_step':
+            continue
+        inside.append(name)
+        can = _canonical(rel)
+        m = _BN_RE.match(can)
+        if m:
+            bn_have.setdefault(m.group(1), {}).setdefault(int(m.group(2) or 0), {})[m.group(3)] = name
         else:
-            strange.append('%s %s' % (name, entries[name]['shape']))
-    if strange:
-        raise CheckpointError('variables under %s that the inference graph does not have:\n  %s'
-                              % (GRAPH_PREFIX, '\n  '.join(strange)))
-    raw = read_checkpoint(prefix, names=set(pick), verify_crc=verify_crc)
-    w = {pick[k]: np.asarray(v, np.float32) for k, v in raw.items()}
-    check_weights(w, hp)      # lists every missing / mis-shaped variable
-    return w
+            cand.setdefault(can, []).append(name)
+    mapping, problems = {}, []
+    bn_want = {}
+    for name, shape, _ in specs:
+        can = _canonical(name)
+        m = _BN_RE.match(can)
+        if m:
+            bn_want.setdefault(m.group(1), {}).setdefault(int(m.group(2) or 0), []).append((name, m.group(3), shape))
+            continue
+        names = cand.get(can, [])
+        fits = [n for n in names if tuple(entries[n]['shape']) == tuple(shape)]
+        if len(fits) == 1:
+            mapping[name] = fits[0]
+        elif not names:
+            problems.append('missing %s %s' % (name, tuple(shape)))
+        elif not fits:
+            problems.append('shape %s: got %s want %s' % (name, ', '.join(str(tuple(entries[n]['shape'])) for n in names),
+                                                          tuple(shape)))
+        else:
+            problems.append('ambiguous %s: %s' % (name, ', '.join(fits)))
+    for scope, want in bn_want.items():
+        have = bn_have.get(scope, {})
+        have_order = sorted(have)
+        for k, idx in enumerate(sorted(want)):
+            src = have[have_order[k]] if k < len(have_order) else {}
+            for name, part, shape in want[idx]:
+                n = src.get(part)
+                if n is None:
+                    problems.append('missing %s %s' % (name, tuple(shape)))
+                elif tuple(entries[n]['shape']) != tuple(shape):
+                    problems.append('shape %s: got %s (%s) want %s' % (name, tuple(entries[n]['shape']), n, tuple(shape)))
+                else:
+                    mapping[name] = n
+    used = set(mapping.values())
+    leftovers = [n for n in inside if n not in used]
+    return mapping, problems, leftovers
 
 
-def save_tacotron_weights(prefix, w):
-    """Weights dict -> bundle under the reference's variable names (readable by tf.train.Saver)."""
-    write_checkpoint(prefix, {GRAPH_PREFIX + k: np.asarray(v, np.float32) for k, v in w.items()})
+def load_tacotron_weights(prefix, hp=None, verify_crc=True, verbose=False, strict=False, report=None):
+    """The inference-graph variables of a checkpoint the reference saved (model/tacotron.py:169; restored by
+    synthesizer.py:32-34), as the {name relative to model/inference/: float32 array} dict the engine takes. Variables
+    are matched by pattern and shape (match_variables). Missing or mis-shaped variables raise, with every problem and
+    every unclaimed variable listed; unclaimed variables alone are reported (`verbose` prints the whole name mapping;
+    `report`, a dict, receives 'mapping', 'leftovers', 'renamed') and raise only under `strict`."""
+    entries, _ = read_index(prefix)
+    mapping, problems, leftovers = match_variables(entries, hp)
+    renamed = {k: v for k, v in mapping.items() if v != GRAPH_PREFIX + k}
+    if report is not None:
+        report.update(mapping=dict(mapping), leftovers=list(leftovers), renamed=renamed)
+    if verbose:
+        for k in sorted(mapping):
+            print('  %s <- %s%s' % (k, mapping[k], '' if k not in renamed else '   (renamed)'))
+    left_txt = ['%s %s' % (n, tuple(entries[n]['shape'])) for n in leftovers]
+    if problems:
+        raise CheckpointError('checkpoint %s does not fit the inference graph:\n  %s%s' % (
+            prefix, '\n  '.join(problems),
+            ('\nvariables under %s that nothing claimed:\n  %s' % (GRAPH_PREFIX, '\n  '.join(left_txt))) if left_txt else ''))
+    if left_txt:
+        msg = 'variables under %s that the inference graph does not have:\n  %s' % (GRAPH_PREFIX, '\n  '.join(left_txt))
+        if strict:
+            raise CheckpointError(msg)
+        print('load_tacotron_weights: ' + msg)
+    raw = read_checkpoint(prefix, names=set(mapping.values()), verify_crc=verify_crc)
+    return {k: np.asarray(raw[v], np.float32) for k, v in mapping.items()}
+
+
+def save_tacotron_weights(prefix, w, spelling='tf1.15'):
+    """Weights dict -> bundle under the reference's variable names (readable by tf.train.Saver). `spelling` selects
+    among the name variants of SURVEY.md Appendix C that the loader accepts: 'tf1.15' (the names of weights.py),
+    'residual_wrapper' (`cell_{1,2}/residual_wrapper/gru_cell/...`), 'global_bn' (batch-norm scopes numbered across
+    the whole graph in creation order instead of per enclosing scope)."""
+    from .weights import variable_specs  # noqa: F401  (creation order of the dict is the graph's)
+    out, n_bn, seen = {}, 0, {}
+    for k, v in w.items():
+        name = k
+        if spelling == 'residual_wrapper':
+            name = re.sub(r'(multi_rnn_cell/cell_[12]/)(gru_cell/)', r'\1residual_wrapper/\2', name)
+        elif spelling == 'global_bn':
+            m = _BN_RE.match(name)
+            if m:
+                scope = m.group(1) + 'batch_normalization' + ('_' + m.group(2) if m.group(2) else '')
+                if scope not in seen:
+                    seen[scope] = n_bn
+                    n_bn += 1
+                name = '%sbatch_normalization%s/%s' % (m.group(1), '_%d' % seen[scope] if seen[scope] else '', m.group(3))
+        elif spelling != 'tf1.15':
+            raise ValueError('unknown spelling %r' % spelling)
+        out[GRAPH_PREFIX + name] = np.asarray(v, np.float32)
+    write_checkpoint(prefix, out)

@@ -60,7 +60,7 @@ def test_corruption_is_detected(tmp_path):
         C.read_checkpoint(prefix)
 
 
-def test_tacotron_variables_roundtrip_and_diagnostics(tmp_path):
+def test_tacotron_variables_roundtrip_and_diagnostics(tmp_path, capsys):
     """A training checkpoint as model/tacotron.py:169 leaves it: inference variables + Adam slots + counters."""
     hp = HParams()
     w = init_weights(hp, seed=3)
@@ -84,13 +84,82 @@ def test_tacotron_variables_roundtrip_and_diagnostics(tmp_path):
     with pytest.raises(Exception) as ei:
         C.load_tacotron_weights(prefix, hp)
     assert 'memory_layer/kernel' in str(ei.value) and 'dense/bias' in str(ei.value)
-    # an unknown variable inside the graph scope is reported, not silently dropped
+    # an unknown variable inside the graph scope is listed, not silently dropped and not fatal (strict: fatal)
     odd = dict(full)
     odd[C.GRAPH_PREFIX + 'post_cbhg/extra/kernel'] = np.zeros((2, 2), np.float32)
     C.write_checkpoint(prefix, odd)
+    rep = {}
+    back = C.load_tacotron_weights(prefix, hp, report=rep)
+    assert rep['leftovers'] == [C.GRAPH_PREFIX + 'post_cbhg/extra/kernel'] and not rep['renamed']
+    assert 'post_cbhg/extra/kernel' in capsys.readouterr().out
+    assert np.array_equal(back['dense/kernel'], w['dense/kernel'])
     with pytest.raises(C.CheckpointError) as ei:
-        C.load_tacotron_weights(prefix, hp)
+        C.load_tacotron_weights(prefix, hp, strict=True)
     assert 'post_cbhg/extra/kernel' in str(ei.value)
     # save side
     C.save_tacotron_weights(prefix, w)
     assert np.array_equal(C.load_tacotron_weights(prefix, hp)['dense/kernel'], w['dense/kernel'])
+
+
+@pytest.mark.parametrize('spelling', ['tf1.15', 'residual_wrapper', 'global_bn'])
+def test_variable_name_spellings(tmp_path, spelling, capsys):
+    """the `residual_wrapper/` segment of cell_1 / cell_2 (model/decoder.py:28-32) is
+    TF-version dependent and batch-norm scopes are auto-numbered; the loader matches by pattern and shape, so every
+    spelling loads to the same weight set, and `verbose` prints the name mapping."""
+    hp = HParams()
+    w = init_weights(hp, seed=5, randomize_bn=True)
+    prefix = str(tmp_path / 'model.ckpt-9')
+    C.save_tacotron_weights(prefix, w, spelling=spelling)
+    names, _ = C.read_index(prefix)
+    if spelling == 'residual_wrapper':
+        assert any('/cell_1/residual_wrapper/gru_cell/' in n for n in names)
+        assert not any('/cell_1/gru_cell/' in n for n in names)
+    if spelling == 'global_bn':
+        assert C.GRAPH_PREFIX + 'post_cbhg/batch_normalization_27/gamma' in names
+        assert C.GRAPH_PREFIX + 'post_cbhg/batch_normalization_1/gamma' not in names
+    rep = {}
+    back = C.load_tacotron_weights(prefix, hp, verbose=True, report=rep)
+    assert set(back) == set(w) and not rep['leftovers']
+    for k in w:
+        assert np.array_equal(back[k], w[k]), k
+    assert bool(rep['renamed']) == (spelling != 'tf1.15')
+    out = capsys.readouterr().out
+    assert 'dense/kernel <- model/inference/dense/kernel' in out
+    if spelling != 'tf1.15':
+        assert '(renamed)' in out
+
+
+def test_mismatched_bn_count_and_shapes_are_named(tmp_path):
+    hp = HParams()
+    w = init_weights(hp, seed=5)
+    prefix = str(tmp_path / 'm')
+    full = {C.GRAPH_PREFIX + k: v for k, v in w.items()}
+    for part in ('gamma', 'beta', 'moving_mean', 'moving_variance'):      # one conv-bank BN short
+        del full[C.GRAPH_PREFIX + 'encoder_cbhg/conv_bank/batch_normalization_15/' + part]
+    full[C.GRAPH_PREFIX + 'post_cbhg/batch_normalization/gamma'] = np.ones(7, np.float32)
+    C.write_checkpoint(prefix, full)
+    with pytest.raises(C.CheckpointError) as ei:
+        C.load_tacotron_weights(prefix, hp)
+    msg = str(ei.value)
+    assert 'missing encoder_cbhg/conv_bank/batch_normalization_15/gamma' in msg
+    assert 'shape post_cbhg/batch_normalization/gamma' in msg
+
+
+def test_tensor_crc_checked_by_default(tmp_path):
+    """A flipped bit in the data shard of a real-size weight set is caught by the default load (vectorised CRC32C
+    agrees with the byte-wise definition on large inputs)."""
+    rng = np.random.default_rng(1)
+    blob = rng.integers(0, 256, 300001, dtype=np.uint8).tobytes()
+    assert C.crc32c(blob) == C._crc_scalar(0xFFFFFFFF, blob) ^ 0xFFFFFFFF
+    assert C.crc32c(blob[1000:], C.crc32c(blob[:1000])) == C.crc32c(blob)
+    hp = HParams()
+    w = init_weights(hp, seed=2)
+    prefix = str(tmp_path / 'model.ckpt-3')
+    C.save_tacotron_weights(prefix, w)
+    path = prefix + '.data-00000-of-00001'
+    d = bytearray(open(path, 'rb').read())
+    d[len(d) // 2] ^= 4
+    open(path, 'wb').write(bytes(d))
+    with pytest.raises(C.CheckpointError, match='CRC32C'):
+        C.load_tacotron_weights(prefix, hp)
+    assert C.load_tacotron_weights(prefix, hp, verify_crc=False).keys() == w.keys()
