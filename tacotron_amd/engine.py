@@ -86,7 +86,13 @@ class TacoEngine:
 
     def _dev(self, x, dtype):
         t = torch.as_tensor(np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x)
-        t = t.to(device=self.device, dtype=dtype).contiguous()
+        if t.device.type == 'cpu':
+            # host data: the upload is issued on the engine's own stream, so it is ordered before the kernels that
+            # read it also when the engine runs detached from torch's current stream
+            with torch.cuda.stream(self.stream):
+                t = t.to(device=self.device, dtype=dtype).contiguous()
+        else:
+            t = t.to(device=self.device, dtype=dtype).contiguous()
         t.record_stream(self.stream)
         return t
 

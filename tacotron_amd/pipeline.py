@@ -10,26 +10,101 @@ More than 4 streams only overlap when the process may open more hardware queues 
 set GPU_MAX_HW_QUEUES (8 is what bench.py uses) before the HIP runtime loads, i.e. before `import torch`."""
 import collections
 
+import numpy as np
 import torch
 
 from .engine import TacoEngine
+from .shard import gather_order, plan_batches
 
 
 class SynthesisPipeline:
-    def __init__(self, weights, hp=None, device=0, depth=6, decode_mode=2):
+    """`devices`: the GPUs of the node to shard a job over (utterances are independent, weights are
+    replicated, no collective; BASELINE.json north_star: "utterance batches shard trivially across the 8 GPUs of one
+    node"). One set of `depth` engines is created per entry (an id may repeat: two sets on one GPU); `run` uses the
+    first set, `synthesize_sharded` all of them."""
+
+    def __init__(self, weights, hp=None, device=0, depth=6, decode_mode=2, devices=None):
         if depth < 1:
             raise ValueError('depth must be >= 1')
-        self.engines = [TacoEngine(weights, hp, device=device) for _ in range(depth)]
+        self.devices = [device] if devices is None else list(devices)
+        if not self.devices:
+            raise ValueError('devices must name at least one GPU')
+        self.sets = [[TacoEngine(weights, hp, device=d) for _ in range(depth)] for d in self.devices]
+        self.engines = self.sets[0]
         self.hp = self.engines[0].hp
-        for e in self.engines:
-            e.set_decode_graph(decode_mode)
-            e.detached = True
-        self._outs = [{} for _ in self.engines]
+        for es in self.sets:
+            for e in es:
+                e.set_decode_graph(decode_mode)
+                e.detached = True
+        self._set_outs = [[{} for _ in es] for es in self.sets]
+        self._outs = self._set_outs[0]
 
     def close(self):
-        for e in self.engines:
-            e.close()
-        self.engines = []
+        for es in self.sets:
+            for e in es:
+                e.close()
+        self.sets, self.engines = [], []
+
+    def synthesize_sharded(self, ids, lens, batch_size=32, max_iters=None, to_wav=False, gl_iters=None,
+                           keys=('mel', 'linear', 'alignments', 'wav'), trim=False):
+        """One job of N utterances (ids [N, T_in] int32 right-padded with 0, lens [N]) over all engine sets:
+        the utterances are length-sorted and dealt into one contiguous shard per set (shard.shard_by_length), each
+        shard runs as batches of `batch_size` with up to `depth` batches in flight per set, and the results come back
+        in the ORIGINAL order (shard.gather_order) as a list of per-utterance dicts of host arrays (`keys` that were
+        produced, plus `steps_run`). No device talks to another.
+        The padded width is part of the reference's semantics (convolutions and the unmasked attention see the padding,
+        SURVEY.md A.6/A.8), so by default every batch keeps the job's T_in and an utterance's result is bit-identical
+        to the unsharded run; trim=True pads each batch only to its own longest utterance (what a length-sorted
+        feeder is for: less work, the result of the reference run on that smaller batch)."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        lens = np.ascontiguousarray(lens, np.int32)
+        if ids.ndim != 2 or lens.shape != (ids.shape[0],):
+            raise ValueError('ids must be [N, T_in] and lens [N]')
+        if batch_size < 1:
+            raise ValueError('batch_size must be >= 1')
+        shards, plan = plan_batches(lens, len(self.sets), batch_size)
+        tasks = collections.deque(plan)
+        results = [[None] * len(idx) for idx in shards]                 # per set, in shard order
+        filled = [0] * len(self.sets)
+        inflight = [collections.deque() for _ in self.sets]
+        launched = [0] * len(self.sets)
+
+        def collect(si):
+            ei, ev, n = inflight[si].popleft()
+            ev.synchronize()
+            e = self.sets[si][ei]
+            with torch.cuda.device(e.device), torch.cuda.stream(e.stream):
+                o = e.finish(self._set_outs[si][ei], to_wav=to_wav, gl_iters=gl_iters)
+                host = {k: o[k][:n].cpu().numpy() for k in keys if k in o and torch.is_tensor(o[k])}
+            e.stream.synchronize()
+            for b in range(n):
+                r = {k: v[b] for k, v in host.items()}
+                r['steps_run'] = o['steps_run']
+                results[si][filled[si]] = r
+                filled[si] += 1
+
+        while tasks:
+            si, idx = tasks.popleft()
+            es = self.sets[si]
+            if len(inflight[si]) == len(es):
+                collect(si)
+            ei = launched[si] % len(es)
+            launched[si] += 1
+            e = es[ei]
+            b_ids, b_lens = ids[idx], lens[idx]
+            if trim:
+                b_ids = np.ascontiguousarray(b_ids[:, :int(b_lens.max())])
+            with torch.cuda.device(e.device):
+                e.synthesize(b_ids, b_lens, max_iters=max_iters, to_wav=to_wav, gl_iters=gl_iters,
+                             out=self._set_outs[si][ei])
+                ev = torch.cuda.Event()
+                ev.record(e.stream)
+            inflight[si].append((ei, ev, len(idx)))
+        for si in range(len(self.sets)):
+            while inflight[si]:
+                collect(si)
+        flat = [r for rs in results for r in rs]
+        return [flat[j] for j in gather_order(shards)]
 
     def run(self, batches, max_iters=None, to_wav=False, gl_iters=None, to_host=True):
         """`batches`: iterable of (ids [B, T_in] int32, lens [B] int32). Yields one result dict per batch, in order

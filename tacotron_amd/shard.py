@@ -29,3 +29,17 @@ def gather_order(shards):
     inv = np.empty_like(cat)
     inv[cat] = np.arange(len(cat))
     return inv
+
+
+def plan_batches(lengths, world, batch_size):
+    """The launch plan of a sharded job: (shards, tasks) with `shards` from shard_by_length and `tasks` the batches
+    [(rank, index array of <= batch_size utterances)] in issue order - round-robin over the ranks, so that every
+    device receives its k-th batch before any receives its (k+1)-th."""
+    shards = shard_by_length(lengths, world)
+    per_rank = [[idx[lo:lo + batch_size] for lo in range(0, len(idx), batch_size)] for idx in shards]
+    tasks = []
+    for k in range(max((len(b) for b in per_rank), default=0)):
+        for r, batches in enumerate(per_rank):
+            if k < len(batches):
+                tasks.append((r, batches[k]))
+    return shards, tasks

@@ -76,12 +76,33 @@ class Synthesizer:
             out.append(w)
         return np.concatenate(out) if out else np.zeros(0)
 
-    def synthesize_many(self, texts, batch_size=32, depth=4):
+    def synthesize_many(self, texts, batch_size=32, depth=4, devices=None):
         """Extension: an iterable of texts -> generator of (text, waveform) in input order, batches of `batch_size`
-        with up to `depth` batches in flight on this GPU (pipeline.SynthesisPipeline)."""
+        with up to `depth` batches in flight on this GPU (pipeline.SynthesisPipeline).
+        `devices` (a list of GPU ids): the texts are taken as one job, length-sorted and sharded over those GPUs
+        (SynthesisPipeline.synthesize_sharded: one engine set per device, no collective), each batch padded to its
+        own longest text; results still come back in input order."""
         from .pipeline import SynthesisPipeline
-        if getattr(self, '_pipeline', None) is None or len(self._pipeline.engines) != depth:
+        if devices is not None:
+            texts = list(texts)
+            key = ('sharded', tuple(devices), depth)
+            if getattr(self, '_pipeline_key', None) != key:
+                if getattr(self, '_pipeline', None) is not None:
+                    self._pipeline.close()
+                self._pipeline = SynthesisPipeline(self._weights, hparams, depth=depth, devices=devices)
+                self._pipeline_key = key
+            ids, lens = self._ids(texts)
+            res = self._pipeline.synthesize_sharded(ids, lens, batch_size=batch_size, to_wav=True, keys=('wav',),
+                                                    trim=True)
+            for t, r in zip(texts, res):
+                w = audio.pre_emphasis_inv(r['wav'])
+                yield t, w[:audio.find_endpoint(w)]
+            return
+        if getattr(self, '_pipeline', None) is None or getattr(self, '_pipeline_key', None) != ('stream', depth):
+            if getattr(self, '_pipeline', None) is not None:
+                self._pipeline.close()
             self._pipeline = SynthesisPipeline(self._weights, hparams, device=self._device, depth=depth)
+            self._pipeline_key = ('stream', depth)
         groups = []
 
         def batches():

@@ -111,3 +111,29 @@ def test_two_rank_gloo_shard_and_timing(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     out = json.loads(line)
     assert out == {'max_t': 1.5, 'covered': 64, 'once': True, 'per_rank': 32}
+
+
+def test_plan_batches_covers_every_utterance_once():
+    """shard.plan_batches (the launch plan of SynthesisPipeline.synthesize_sharded): contiguous length-sorted shards,
+    batches issued round-robin over the ranks, every utterance exactly once; gather_order restores the input order."""
+    import numpy as np
+    from tacotron_amd.shard import gather_order, plan_batches
+    rng = np.random.default_rng(0)
+    for n, world, bs in [(10, 2, 3), (1, 2, 4), (0, 3, 2), (17, 8, 2), (64, 8, 32), (7, 1, 7)]:
+        lens = rng.integers(2, 50, n)
+        shards, tasks = plan_batches(lens, world, bs)
+        assert len(shards) == world and sorted(np.concatenate(shards).tolist()) == list(range(n))
+        seen = [[] for _ in range(world)]
+        for r, idx in tasks:
+            assert 1 <= len(idx) <= bs
+            seen[r] += idx.tolist()
+        for r in range(world):
+            assert seen[r] == shards[r].tolist()                   # shard order kept, nothing twice
+            assert all(lens[a] >= lens[b] for a, b in zip(seen[r], seen[r][1:]))   # longest first
+        if world > 1 and n >= world:
+            assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+        ranks = [r for r, _ in tasks]
+        first = {r: ranks.index(r) for r in set(ranks)}
+        assert all(first[r] < world for r in first)                # every device gets its first batch up front
+        flat = np.concatenate([lens[s] for s in shards]) if n else np.zeros(0, int)
+        assert np.array_equal(flat[gather_order(shards)], lens)
