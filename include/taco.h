@@ -145,6 +145,17 @@ int taco_postnet(taco_handle h, const float* mel, int32_t B, int32_t T, float* l
 int taco_griffin_lim(taco_handle h, const float* linear, int32_t B, int32_t T, int32_t iters,
                      float* wav, void* ws, size_t ws_bytes, taco_stream_t stream);
 
+/* taco_griffin_lim for callers that cannot allocate and bring no workspace. No counterpart in the reference (its
+ * vocoder is part of the TF graph, tools/audio.py:57-64); it exists for code under HIP graph capture, tight serving
+ * loops and harnesses that forbid hipMalloc. Same kernels, same results, bit for bit, as taco_griffin_lim; the working
+ * set (magnitudes + two frame buffers) lives in a static device array of 20 MiB inside the library, one copy per GPU
+ * the library runs on, held until the process ends, its address resolved at taco_create. Limit: B*T <= 1024 frames
+ * (one utterance of 200 decoder steps x 5 frames); larger inputs are refused (<0, message). The call allocates nothing
+ * (no hipMalloc / hipFree / event or stream creation). All calls on one GPU share that GPU's array: calls that overlap
+ * in time on one GPU (two streams, two handles) race; serialise them. Nothing in the array has to start at zero. */
+int taco_griffin_lim_noalloc(taco_handle h, const float* linear, int32_t B, int32_t T, int32_t iters,
+                             float* wav, taco_stream_t stream);
+
 /* tools/audio.py:44-55 spectrogram_inv up to, not including, pre_emphasis_inv (host): the
  * numpy/librosa flavour of Griffin-Lim (audio.py:167-181) that train.py uses for its evaluation
  * audio: centred, reflect-padded librosa.stft (audio.py:119-134) and librosa.istft with

@@ -32,7 +32,7 @@ class TacoWeightEntry(ctypes.Structure):
 
 
 EXPORTS = ['taco_last_error', 'taco_create', 'taco_destroy', 'taco_workspace_bytes', 'taco_encode',
-           'taco_decode', 'taco_decode_teacher', 'taco_postnet', 'taco_griffin_lim', 'taco_griffin_lim_librosa', 'taco_spectrogram', 'taco_spectrogram_workspace_bytes', 'taco_synthesize', 'taco_timing_begin',
+           'taco_decode', 'taco_decode_teacher', 'taco_postnet', 'taco_griffin_lim', 'taco_griffin_lim_noalloc', 'taco_griffin_lim_librosa', 'taco_spectrogram', 'taco_spectrogram_workspace_bytes', 'taco_synthesize', 'taco_timing_begin',
            'taco_timing_end', 'taco_kernel_name', 'taco_num_kernel_kinds', 'taco_set_decode_graph', 'taco_decode_status', 'taco_debug_conv_gemm',
            'taco_debug_poison_decoder']
 
@@ -68,6 +68,8 @@ def load_library():
     lib.taco_postnet.argtypes = [vp, vp, i32, i32, vp, vp, sz, vp]
     lib.taco_griffin_lim.restype = ctypes.c_int
     lib.taco_griffin_lim.argtypes = [vp, vp, i32, i32, i32, vp, vp, sz, vp]
+    lib.taco_griffin_lim_noalloc.restype = ctypes.c_int
+    lib.taco_griffin_lim_noalloc.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.taco_griffin_lim_librosa.restype = ctypes.c_int
     lib.taco_griffin_lim_librosa.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
     lib.taco_synthesize.restype = ctypes.c_int

@@ -121,6 +121,32 @@ struct taco_ctx {
     std::vector<GraphEntry> graphs;
 };
 
+// ---------------------------------------------------------------------------------------
+// taco_griffin_lim_noalloc: the vocoder for callers that cannot allocate (include/taco.h). Its working set (the
+// target magnitudes and the two ping-pong frame buffers of gl_impl) lives in this file-scope device array instead of a
+// caller workspace. Every GPU the library runs on holds its own copy, at its own address, until the process ends; the
+// name `scratch` is only a host-side stand-in, so the address is asked for once per device at taco_create
+// (hipGetSymbolAddress with that device current) and only that pointer is ever handed to kernels.
+constexpr int NOALLOC_MAX_FRAMES = 1024;    // B * T: one utterance of max_iters = 200 decoder steps x r = 5 frames
+constexpr size_t NOALLOC_MAG_BYTES = ((size_t)NOALLOC_MAX_FRAMES * 1025 * 4 + 255) & ~(size_t)255;
+constexpr size_t NOALLOC_FRAMES_BYTES = ((size_t)NOALLOC_MAX_FRAMES * 2048 * 4 + 255) & ~(size_t)255;   // win <= n_fft
+constexpr size_t NOALLOC_SCRATCH_BYTES = NOALLOC_MAG_BYTES + 2 * NOALLOC_FRAMES_BYTES;                  // 20.0 MiB
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+static void* g_scratch_ptr[64] = {};        // per device, filled by taco_create
+static std::mutex g_scratch_mu;
+
+static int scratch_bind_device(int device) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (device < 0 || device >= 64) return fail("device %d out of range for the static scratch table", device);
+    if (g_scratch_ptr[device]) return 0;
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));     // (the current device is `device`)
+    if (e != hipSuccess || !p)
+        return fail("hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(e));
+    g_scratch_ptr[device] = p;
+    return 0;
+}
+
 namespace {
 
 struct Loader {
@@ -548,6 +574,8 @@ extern "C" int taco_create(const TacoHParams* hp, const TacoWeightEntry* weights
     HIP_OK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail("taco_create: device %d not available (%d visible)", device, ndev);
     HIP_OK(hipSetDevice(device));
+    if (scratch_bind_device(device)) return -1;
+    gl_prepare_device();
 
     taco_ctx* c = new taco_ctx();
     c->hp = p;
@@ -1186,6 +1214,40 @@ extern "C" int taco_griffin_lim(taco_handle h, const float* linear, int32_t B, i
     Carver cv(ws, ws_bytes);
     if (gl_impl(h, linear, B, T, iters, wav, cv, (hipStream_t)stream)) return -1;
     return check_launch("taco_griffin_lim");
+}
+
+extern "C" int taco_griffin_lim_noalloc(taco_handle h, const float* linear, int32_t B, int32_t T, int32_t iters,
+                                        float* wav, taco_stream_t stream) {
+    if (!h || !linear || !wav) return fail("taco_griffin_lim_noalloc: null argument");
+    if (check_dims(B, T)) return -1;
+    if (iters < 0) return fail("taco_griffin_lim_noalloc: iters < 0");
+    if ((long)B * T > NOALLOC_MAX_FRAMES)
+        return fail("taco_griffin_lim_noalloc: B*T = %ld frames, the static scratch holds at most %d "
+                    "(use taco_griffin_lim with a workspace for larger batches)", (long)B * T, NOALLOC_MAX_FRAMES);
+    HIP_OK(hipSetDevice(h->device));
+    void* base = h->device >= 0 && h->device < 64 ? g_scratch_ptr[h->device] : nullptr;
+    if (!base) return fail("taco_griffin_lim_noalloc: no static scratch bound for device %d", h->device);
+    const TacoHParams& hp = h->hp;
+    hipStream_t s = (hipStream_t)stream;
+    // same carve as gl_impl, out of the device's copy of `scratch`; every byte a kernel reads was written earlier in
+    // this call (gl_mag fills mag, the first synthesis fills the first frame buffer), so nothing needs clearing
+    Carver cv(base, NOALLOC_SCRATCH_BYTES);
+    const size_t M = (size_t)B * T;
+    float* mag = cv.take<float>(M * hp.num_freq);
+    float* fa = cv.take<float>(M * hp.win_length);
+    float* fb = cv.take<float>(M * hp.win_length);
+    if (!cv.ok()) return fail("taco_griffin_lim_noalloc: static scratch too small for these hparams");
+    GLPlan p{hp.n_fft, hp.hop_length, hp.win_length, hp.num_freq, h->twiddle, h->window};
+    launch_gl_mag(linear, mag, M * hp.num_freq, hp.min_level_db, hp.ref_level_db, hp.power, s, nullptr);
+    launch_gl_iter(p, fa, mag, fa, B, T, 1, s, nullptr);
+    float* cur = fa;
+    float* nxt = fb;
+    for (int i = 0; i < iters; ++i) {
+        launch_gl_iter(p, cur, mag, nxt, B, T, 0, s, nullptr);
+        std::swap(cur, nxt);
+    }
+    launch_gl_ola(p, cur, wav, B, T, s, nullptr);
+    return check_launch("taco_griffin_lim_noalloc");
 }
 
 // ---------------------------------------------------------------------------------------

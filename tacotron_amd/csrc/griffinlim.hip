@@ -297,6 +297,20 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __r
     }
 }
 
+// More than the default 64 KB of dynamic LDS for gl_iter: the attribute is per device. Called at taco_create (so that
+// an entry point that must not do set-up work finds it done) and, idempotently, by every launch.
+void gl_prepare_device() {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_set[dev]) {
+        for (auto* k : {gl_iter_kernel<false, 0, 0>, gl_iter_kernel<true, 0, 0>, gl_iter_kernel<false, 1200, 300>,
+                        gl_iter_kernel<true, 1200, 300>})
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
+        attr_set[dev] = true;
+    }
+}
+
 void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, float* frames_out, int B, int T,
                     int first, hipStream_t s, Timing* tm, bool librosa, const float* phase_u) {
     if (tm) tm->begin(KK_GL_ITER, s);
@@ -309,15 +323,7 @@ void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, f
     const int runs_per_utt = (T + run - 1) / run;
     const size_t lds = (size_t)((((run - 1) * p.hop + p.win + 3) & ~3) + ((p.win + 3) & ~3)) * 4 +
                        (size_t)(FFT_TW + FFT_N / 2 + GL_WAVES * FFT_LDS) * sizeof(cplx);
-    static bool attr_set[64] = {};   // more than the default 64 KB of dynamic LDS: the attribute is per device
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_set[dev]) {
-        for (auto* k : {gl_iter_kernel<false, 0, 0>, gl_iter_kernel<true, 0, 0>, gl_iter_kernel<false, 1200, 300>,
-                        gl_iter_kernel<true, 1200, 300>})
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024);
-        attr_set[dev] = true;
-    }
+    gl_prepare_device();
     const dim3 grid((unsigned)(B * runs_per_utt));
     const bool dflt = p.win == 1200 && p.hop == 300;
     auto* kern = librosa ? (dflt ? gl_iter_kernel<true, 1200, 300> : gl_iter_kernel<true, 0, 0>)

@@ -160,6 +160,7 @@ void launch_gl_mag(const float* lin, float* mag, size_t n, float min_db, float r
 // exp(2 pi i phase_u), phase_u [B*T][nbins] or null = zero phase).
 void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, float* frames_out, int B, int T,
                     int first, hipStream_t s, Timing* tm, bool librosa = false, const float* phase_u = nullptr);
+void gl_prepare_device();   // per-device kernel attributes of gl_iter (idempotent)
 void launch_gl_ola(const GLPlan& p, const float* frames, float* wav, int B, int T, hipStream_t s, Timing* tm);
 // librosa.istft's output: wav [B][hop (T-1)], window-sum-square normalised, n_fft/2 trimmed from both ends
 void launch_gl_ola_norm(const GLPlan& p, const float* frames, float* wav, int B, int T, hipStream_t s, Timing* tm);

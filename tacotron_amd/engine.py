@@ -211,6 +211,23 @@ class TacoEngine:
         self._leave()
         return wav[0] if squeeze else wav
 
+    def griffin_lim_noalloc(self, linear, iters=None, out=None):
+        """taco_griffin_lim_noalloc: the same vocoder on the library's static device scratch (B*T <= 1024 frames); the
+        call allocates nothing when `out` [B, (T-1)*hop+win] is given. Calls that overlap on one GPU race."""
+        linear = self._dev(linear, torch.float32)
+        squeeze = linear.dim() == 2
+        if squeeze:
+            linear = linear[None]
+        B, T, _ = linear.shape
+        iters = self.hp.griffin_lim_iters if iters is None else int(iters)
+        _, hop, win = self.hp.stft_params()
+        wav = out if out is not None else self._empty((B, (T - 1) * hop + win,), torch.float32)
+        self._enter()
+        self._check(self.lib.taco_griffin_lim_noalloc(self.handle, linear.data_ptr(), B, T, iters, wav.data_ptr(),
+                                                      self._s))
+        self._leave()
+        return wav[0] if squeeze and out is None else wav
+
     def griffin_lim_librosa(self, linear, phase_u=None, iters=None):
         """tools/audio.py:44-55,167-181 without the final pre_emphasis_inv: linear [B, T, num_freq] (or [T, num_freq])
         normalised spectrogram, phase_u same shape of uniform [0, 1) draws (None = zero phase) ->
