@@ -402,8 +402,10 @@ def main():
             res['value_at_inherited_hw_queues'] = {'value': child['value'], 'ms_per_step': child['ms_per_step'],
                                                    'gpu_max_hw_queues': HWQ_INHERITED}
         except Exception as ex:                    # reported, never fatal for the headline line
-            res['value_at_inherited_hw_queues'] = {'error': repr(ex)[:200],
-                                                   'stderr_tail': (cp.stderr[-400:] if cp is not None else None)}
+            res['value_at_inherited_hw_queues'] = {
+                'error': repr(ex)[:200], 'rc': cp.returncode if cp is not None else None,
+                'stdout_tail': (cp.stdout[-300:] if cp is not None else None),
+                'stderr_tail': (cp.stderr[-400:] if cp is not None else None)}
     if rank == 0:
         print(json.dumps(res))
 
