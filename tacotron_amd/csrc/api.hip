@@ -104,6 +104,7 @@ struct taco_ctx {
     float* attn_v = nullptr;
     float* twiddle = nullptr;
     float* window = nullptr;
+    float* gl_image = nullptr;     // LDS image of gl_iter2's tables (window | twiddle tables), device
     Timing timing;
     bool timing_on = false;
     int decode_mode = 2;           // 0 eager per-stage kernels, 1 captured hipGraph of them, 2 persistent kernel
@@ -689,8 +690,9 @@ extern "C" int taco_create(const TacoHParams* hp, const TacoWeightEntry* weights
         for (int n = 0; n < p.win_length; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / p.win_length));
         c->twiddle = L.upload(tw);
         c->window = L.upload(win);
+        c->gl_image = L.upload(gl_lds_image(tw, win));
         c->sync_words = reinterpret_cast<unsigned long long*>(L.upload(std::vector<float>(8 * 32, 0.f)));
-        ok = c->twiddle && c->window && c->sync_words;
+        ok = c->twiddle && c->window && c->gl_image && c->sync_words;
         if (ok && (hipHostMalloc(reinterpret_cast<void**>(&c->host_status), 64, hipHostMallocDefault) != hipSuccess ||
                    hipEventCreateWithFlags(&c->status_ev, hipEventDisableTiming) != hipSuccess)) {
             L.err = "cannot allocate the decoder status mirror";
@@ -1118,7 +1120,7 @@ static int gl_impl(taco_ctx* c, const float* linear, int B, int T, int iters, fl
     float* fa = ws.take<float>(M * hp.win_length);
     float* fb = ws.take<float>(M * hp.win_length);
     if (!ws.ok()) return fail("taco_griffin_lim: workspace too small");
-    GLPlan p{hp.n_fft, hp.hop_length, hp.win_length, hp.num_freq, c->twiddle, c->window};
+    GLPlan p{hp.n_fft, hp.hop_length, hp.win_length, hp.num_freq, c->twiddle, c->window, c->gl_image};
     launch_gl_mag(linear, mag, M * hp.num_freq, hp.min_level_db, hp.ref_level_db, hp.power, s, tm);
     launch_gl_iter(p, fa, mag, fa, B, T, 1, s, tm);     // y0 = istft(mag, zero phase) (audio.py:191)
     float* cur = fa;
@@ -1141,7 +1143,7 @@ static int gl_librosa_impl(taco_ctx* c, const float* linear, const float* phase_
     float* fa = ws.take<float>(M * hp.win_length);
     float* fb = ws.take<float>(M * hp.win_length);
     if (!ws.ok()) return fail("taco_griffin_lim_librosa: workspace too small");
-    GLPlan p{hp.n_fft, hp.hop_length, hp.win_length, hp.num_freq, c->twiddle, c->window};
+    GLPlan p{hp.n_fft, hp.hop_length, hp.win_length, hp.num_freq, c->twiddle, c->window, c->gl_image};
     launch_gl_mag(linear, mag, M * hp.num_freq, hp.min_level_db, hp.ref_level_db, hp.power, s, tm);
     launch_gl_iter(p, fa, mag, fa, B, T, 1, s, tm, true, phase_u);   // y = istft(S * angles) (audio.py:175-177)
     float* cur = fa;
@@ -1194,7 +1196,7 @@ extern "C" int taco_spectrogram(taco_handle h, const float* wav, int32_t B, int3
     float* mag = cv.take<float>(M * ldm);
     if (!cv.ok()) return fail("taco_spectrogram: workspace too small");
     if (ldm != hp.num_freq) HIP_OK(hipMemsetAsync(mag, 0, M * ldm * sizeof(float), s));   // zero K padding
-    GLPlan p{hp.n_fft, hp.hop_length, hp.win_length, hp.num_freq, h->twiddle, h->window};
+    GLPlan p{hp.n_fft, hp.hop_length, hp.win_length, hp.num_freq, h->twiddle, h->window, h->gl_image};
     launch_stft_center(p, wav, B, n_samples, (int)T, preemphasis, hp.ref_level_db, hp.min_level_db, mag, ldm, linear, s, tm);
     if (mel) {
         const ConvW& w = h->mel_proj;   // _linspect_to_melspect + _amp_to_db - ref + _normalize (audio.py:78-79)
@@ -1237,7 +1239,7 @@ extern "C" int taco_griffin_lim_noalloc(taco_handle h, const float* linear, int3
     float* fa = cv.take<float>(M * hp.win_length);
     float* fb = cv.take<float>(M * hp.win_length);
     if (!cv.ok()) return fail("taco_griffin_lim_noalloc: static scratch too small for these hparams");
-    GLPlan p{hp.n_fft, hp.hop_length, hp.win_length, hp.num_freq, h->twiddle, h->window};
+    GLPlan p{hp.n_fft, hp.hop_length, hp.win_length, hp.num_freq, h->twiddle, h->window, h->gl_image};
     launch_gl_mag(linear, mag, M * hp.num_freq, hp.min_level_db, hp.ref_level_db, hp.power, s, nullptr);
     launch_gl_iter(p, fa, mag, fa, B, T, 1, s, nullptr);
     float* cur = fa;

@@ -28,6 +28,41 @@ TACO_HD cplx cadd(cplx a, cplx b) { return a + b; }
 TACO_HD cplx csub(cplx a, cplx b) { return a - b; }
 TACO_HD cplx cmul(cplx a, cplx b) { return __builtin_elementwise_fma(a.yy, cplx{-b.y, b.x}, a.xx * b); }
 TACO_HD cplx cconj(cplx a) { return cplx{a.x, -a.y}; }
+// a + (-i) d and a + (+i) d as ONE packed add: the rotation is the instruction's operand selection (second source
+// half-swapped) and negation of one half. Left to the compiler, the rotated value is built with a move and a sign flip
+// per butterfly (two extra instructions in each of the 40 radix-4 butterflies of a frame). Same arithmetic, bit for bit.
+#if defined(__HIP_DEVICE_COMPILE__)
+TACO_HD cplx cadd_mi(cplx a, cplx d) {
+    cplx r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+}
+TACO_HD cplx cadd_pi(cplx a, cplx d) {
+    cplx r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+}
+// a * b and a * conj(b) for a twiddle b that comes from memory: the half-swapped, half-negated second factor of the
+// FMA is operand selection as well (the compiler builds it with a move and a sign flip per product; for compile-time
+// constant twiddles cmul folds them into literals and stays the better form). Bit-identical to cmul / cmul(a, cconj(b)).
+TACO_HD cplx cmul_v(cplx a, cplx b) {
+    cplx t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+TACO_HD cplx cmul_vc(cplx a, cplx b) {
+    cplx t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+#else
+TACO_HD cplx cadd_mi(cplx a, cplx d) { return cplx{a.x + d.y, a.y - d.x}; }
+TACO_HD cplx cadd_pi(cplx a, cplx d) { return cplx{a.x - d.y, a.y + d.x}; }
+TACO_HD cplx cmul_v(cplx a, cplx b) { return cmul(a, b); }
+TACO_HD cplx cmul_vc(cplx a, cplx b) { return cmul(a, cconj(b)); }
+#endif
 #else
 struct cplx {
     float x, y;
@@ -36,6 +71,10 @@ TACO_HD cplx cadd(cplx a, cplx b) { return {a.x + b.x, a.y + b.y}; }
 TACO_HD cplx csub(cplx a, cplx b) { return {a.x - b.x, a.y - b.y}; }
 TACO_HD cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 TACO_HD cplx cconj(cplx a) { return {a.x, -a.y}; }
+TACO_HD cplx cadd_mi(cplx a, cplx d) { return {a.x + d.y, a.y - d.x}; }
+TACO_HD cplx cadd_pi(cplx a, cplx d) { return {a.x - d.y, a.y + d.x}; }
+TACO_HD cplx cmul_v(cplx a, cplx b) { return cmul(a, b); }
+TACO_HD cplx cmul_vc(cplx a, cplx b) { return cmul(a, cconj(b)); }
 #endif
 
 constexpr int FFT_N = 1024;                 // complex length
@@ -51,11 +90,10 @@ TACO_HD void dft4(cplx& a0, cplx& a1, cplx& a2, cplx& a3) {
     const cplx v1 = csub(a0, a2);
     const cplx v2 = cadd(a1, a3);
     const cplx d = csub(a1, a3);
-    const cplx v3 = INV ? cplx{-d.y, d.x} : cplx{d.y, -d.x};   // d * (+i) : d * (-i)
     a0 = cadd(v0, v2);
-    a1 = cadd(v1, v3);
+    a1 = INV ? cadd_pi(v1, d) : cadd_mi(v1, d);   // v1 + d * (+i) : v1 + d * (-i)
     a2 = csub(v0, v2);
-    a3 = csub(v1, v3);
+    a3 = INV ? cadd_mi(v1, d) : cadd_pi(v1, d);
 }
 
 // w16^n = exp(-2 pi i n / 16) for the products n = a2 * c1 that occur (0,1,2,3,4,6,9)
@@ -153,7 +191,7 @@ TACO_HD void fft_pass2(cplx (&v)[16], cplx* lds, int lane, const cplx* T2) {
 #endif
     for (int i = 1; i < 16; ++i) {
         const cplx w = T2[(i - 1) * 16 + (lane & 15)];
-        v[i] = cmul(v[i], INV ? cconj(w) : w);
+        v[i] = INV ? cmul_vc(v[i], w) : cmul_v(v[i], w);
     }
     dft16<INV>(v);
     const int base = (lane >> 4) * 256 + (lane & 15);
@@ -174,7 +212,7 @@ TACO_HD void fft_pass3(cplx (&v)[16], int lane, const cplx* T3) {
 #endif
         for (int i = 1; i < 4; ++i) {
             const cplx w = T3[(i - 1) * 256 + lane + 64 * q];
-            v[q + 4 * i] = cmul(v[q + 4 * i], INV ? cconj(w) : w);
+            v[q + 4 * i] = INV ? cmul_vc(v[q + 4 * i], w) : cmul_v(v[q + 4 * i], w);
         }
         dft4<INV>(v[q], v[q + 4], v[q + 8], v[q + 12]);
     }
@@ -194,7 +232,7 @@ TACO_HD void rfft_split(cplx Zk, cplx Zn, cplx Wk, cplx& Xk, cplx& Xn) {
     const cplx E = chalf_sum(Zk, cn);
     const cplx D = chalf_diff(Zk, cn);
     const cplx O = {D.y, -D.x};              // D / i
-    const cplx P = cmul(Wk, O);
+    const cplx P = cmul_v(Wk, O);
     Xk = cadd(E, P);
     Xn = cconj(csub(E, P));
 }
@@ -205,7 +243,7 @@ TACO_HD void irfft_merge(cplx Yk, cplx Yn, cplx Wk, cplx& Zk, cplx& Zn) {
     const cplx cn = cconj(Yn);
     const cplx E = chalf_sum(Yk, cn);
     const cplx D = chalf_diff(Yk, cn);
-    const cplx O = cmul(D, cconj(Wk));
+    const cplx O = cmul_vc(D, Wk);
     const cplx iO = {-O.y, O.x};
     Zk = cadd(E, iO);
     Zn = cconj(csub(E, iO));

@@ -13,6 +13,8 @@
 // -> merge -> inverse -> window -> store. The waves never meet at a barrier inside the frame loop; a wave's passes
 // exchange data through its private, padded LDS buffer.
 // HBM/L2 traffic per frame and iteration: 4.1 KB magnitudes + ~5.7 KB frame reads + 4.8 KB frame writes.
+#include <cstdlib>
+
 #include "kernels.h"
 #include "fft_core.h"
 
@@ -297,6 +299,374 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __r
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// gl_iter2: the iteration of the TF flavour at the default geometry (compile-time window / hop), two frames per wave.
+// Same arithmetic per frame as gl_iter_kernel<false, WIN, HOP>; what changes is the order of issue. A frame is a chain
+// of seven stages separated by exchanges through the wave's LDS buffer (write 16, read 16), and with one frame per wave
+// every exchange is an exposed LDS round trip: at two waves per SIMD the counters show the waves parked in s_waitcnt
+// for a third of their life and the VALU busy about 40 % of the time. Here a wave carries two independent frames A and
+// B through the stages half a stage apart, A.math -> A.write -> A.read | B.math -> B.write -> B.read | A.math ..., so
+// the round trip of one frame's exchange lies under the other frame's arithmetic. Both frames share ONE exchange buffer:
+// the LDS executes a wave's instructions in order, so B's writes (issued after A's reads) cannot overtake them.
+// Every read group is made to land (GL2_LAND) right before the other frame's writes are issued: at that point it is the
+// newest group outstanding, so its wait is a plain lgkmcnt(0) on data requested a whole stage earlier, not a counted
+// wait entangled with the other frame's fresher operations.
+// Zero padding is used: the 1200 windowed samples fill complex points 0..599, so inputs 10..15 of the forward
+// transform's first radix-16 pass are zero (dft16_fwd_in10); of the inverse transform only outputs 0..9 are stored and
+// the compiler drops the rest of the last pass. Bins 0 / 512 / 1024 take the generic pair formulas (k = 0 pairs with
+// itself: Z[1024] = Z[0], W^0 = 1, the partner slot is a dummy entry behind the buffer), so the body has no branch.
+#define GL2_LAND(v)                                                                                               \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) asm volatile("" : "+v"(v[i_]));                         \
+    } while (0)
+
+// first-stage DFT-16 of a vector whose elements 10..15 are zero (natural order in and out, as dft16<false>)
+__device__ __forceinline__ void dft16_fwd_in10(cplx (&v)[16]) {
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2) {          // (v[a2], v[4+a2], v[8+a2], 0)
+        const cplx v0 = cadd(v[a2], v[8 + a2]);
+        const cplx v1 = csub(v[a2], v[8 + a2]);
+        const cplx v2 = v[4 + a2];
+        v[a2] = cadd(v0, v2);
+        v[4 + a2] = cadd_mi(v1, v2);          // v1 + v2 * (-i)
+        v[8 + a2] = csub(v0, v2);
+        v[12 + a2] = cadd_pi(v1, v2);
+    }
+#pragma unroll
+    for (int a2 = 2; a2 < 4; ++a2) {          // (v[a2], v[4+a2], 0, 0)
+        const cplx v0 = v[a2];
+        const cplx v2 = v[4 + a2];
+        v[a2] = cadd(v0, v2);
+        v[4 + a2] = cadd_mi(v0, v2);
+        v[8 + a2] = csub(v0, v2);
+        v[12 + a2] = cadd_pi(v0, v2);
+    }
+#pragma unroll
+    for (int c1 = 1; c1 < 4; ++c1)
+#pragma unroll
+        for (int a2 = 1; a2 < 4; ++a2) v[4 * c1 + a2] = cmul(v[4 * c1 + a2], w16<false>(a2 * c1));
+#pragma unroll
+    for (int c1 = 0; c1 < 4; ++c1) dft4<false>(v[4 * c1], v[4 * c1 + 1], v[4 * c1 + 2], v[4 * c1 + 3]);
+    cplx o[16];
+#pragma unroll
+    for (int c1 = 0; c1 < 4; ++c1)
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) o[c1 + 4 * c2] = v[4 * c1 + c2];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = o[c];
+}
+
+#ifdef GL_STAMPS   // diagnostic build: s_memtime stamps of wave 0 of one workgroup (never in the shipped library)
+__device__ unsigned long long gl_dbg[64];
+#define GL_STAMP(i)                                                                                   \
+    do {                                                                                              \
+        if (blockIdx.x == GL_STAMP_WG && tid == 0) {                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+            gl_dbg[i] = __builtin_amdgcn_s_memtime();                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                             \
+    } while (0)
+#ifndef GL_STAMP_WG
+#define GL_STAMP_WG 1000
+#endif
+#else
+#define GL_STAMP(i) do {} while (0)
+#endif
+
+constexpr int GL2_LDS = FFT_LDS + 8;    // + the dummy partner slot of bin pair (0, 1024) at fft_pad(1024) = 1088
+
+template <int WIN, int HOP>
+struct GL2Frame {
+    cplx v[16];
+    cplx z512;
+    const float* ys;         // the frame's samples in the workgroup's LDS segment
+    float* out;              // its row of frames_out
+};
+
+template <int WIN, int HOP>
+__global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __restrict__ frames_in,
+                                                                const float* __restrict__ mag,
+                                                                float* __restrict__ frames_out,
+                                                                const float* __restrict__ lds_image, int B, int T,
+                                                                int nbins, int run, int runs_per_utt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gl_smem[];
+    static_assert(WIN % 4 == 0 && HOP % 4 == 0 && WIN % HOP == 0 && WIN / 2 <= 640 && WIN / 2 > 576,
+                  "gl_iter2 is written for windows of 1154..1280 samples (ten live inputs per lane)");
+    constexpr int HALF = WIN / 2;
+    const int seg_cap = (run - 1) * HOP + WIN;
+    float* yseg = reinterpret_cast<float*>(gl_smem);
+    float* win_s = yseg + ((seg_cap + 3) & ~3);
+    cplx* tw_s = reinterpret_cast<cplx*>(win_s + WIN);
+    const cplx* T2 = tw_s;
+    const cplx* T3 = tw_s + FFT_T2;
+    cplx* wk_s = tw_s + FFT_TW;
+    cplx* fft_s = wk_s + FFT_N / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    cplx* lds = fft_s + wave * GL2_LDS;
+
+    const int b = blockIdx.x / runs_per_utt;
+    const int m0 = (blockIdx.x - b * runs_per_utt) * run;
+    const int nfr = min(run, T - m0);
+    const long fb = (long)b * T;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+
+    GL_STAMP(0);
+    // target magnitudes of the lane's bin pairs (k, 1024 - k), k = lane + 64 j, for the two frames of the wave's first
+    // pair: requested before anything else, so that the loads (from HBM: the magnitudes of a batch do not stay in any
+    // cache between iterations) are long back when the first re-phasing needs them; the next pair's are requested when
+    // this pair's are dead (after m4)
+    float mkA[8], mnA[8], m512A, mkB[8], mnB[8], m512B;
+    auto load_mag = [&](float (&mk)[8], float (&mn)[8], float& m512, int fi) {
+        const float* mg = mag + (fb + m0 + fi) * nbins;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = lane + 64 * j;
+            mk[j] = mg[k];
+            mn[j] = mg[FFT_N - k];
+        }
+        m512 = mg[FFT_N / 2];
+    };
+    load_mag(mkA, mnA, m512A, min(wave, nfr - 1));
+    load_mag(mkB, mnB, m512B, min(wave + GL_WAVES, nfr - 1));
+    // window + twiddle tables: a straight copy of the image taco_create built (WIN + 2 (FFT_TW + 512) floats). The
+    // loads are issued here, the LDS stores follow the gather's loads below: one memory round trip for both.
+    constexpr int N4 = (WIN + 2 * (FFT_TW + FFT_N / 2)) / 4;
+    constexpr int TSTEPS = (N4 + GL_THREADS - 1) / GL_THREADS;
+    f4v timg[TSTEPS];
+#pragma unroll
+    for (int k = 0; k < TSTEPS; ++k) {
+        const int i = tid + GL_THREADS * k;
+        if (i < N4) timg[k] = reinterpret_cast<const f4v*>(lds_image)[i];
+    }
+    auto store_tables = [&]() {
+#pragma unroll
+        for (int k = 0; k < TSTEPS; ++k) {
+            const int i = tid + GL_THREADS * k;
+            if (i < N4) reinterpret_cast<f4v*>(win_s)[i] = timg[k];
+        }
+    };
+    GL_STAMP(1);
+    {
+        // the samples the run covers: y[HOP*m0 + i] = ((f[q-3] + f[q-2]) + f[q-1]) + f[q], the frames of the previous
+        // iteration that cover the sample in ascending order (frames outside the utterance count as zero); four samples
+        // per lane and step, the four loads issued together. A run whose samples are covered by frames of the
+        // utterance only (all but the first and the last run of an utterance) takes the loads as they are: four
+        // addresses a constant apart, no range tests; the others clamp the frame index and replace what was out of
+        // range by zero. A sample gets the same sum either way, so the result does not depend on the run length.
+        const int seg = (nfr - 1) * HOP + WIN;
+        constexpr int NOVER = WIN / HOP;
+        static_assert(NOVER == 4, "the gather is written for four covering frames");
+        const float* fu = frames_in + fb * WIN;
+        if (m0 >= NOVER - 1 && m0 + nfr + NOVER - 2 <= T - 1) {
+            const float* base = fu + (long)(m0 - (NOVER - 1)) * WIN + HOP * (NOVER - 1);   // frame q-3 at offset r + 3 HOP
+            // every load of the thread is issued before the first sum: one memory round trip for the whole segment
+            // (the registers are free here, the transform's working set is not live yet)
+            constexpr int STEPS = ((GL_RUN - 1) * HOP + WIN + 4 * GL_THREADS - 1) / (4 * GL_THREADS);
+            f4v ga[STEPS], gb[STEPS], gc[STEPS], gd[STEPS];
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                const int i = 4 * (tid + GL_THREADS * st);
+                if (i < seg) {
+                    const int qq = i / HOP;
+                    const float* p0 = base + qq * (WIN - HOP) + i;        // = base + qq*WIN + (i - qq*HOP)
+                    ga[st] = *reinterpret_cast<const f4v*>(p0);
+                    gb[st] = *reinterpret_cast<const f4v*>(p0 + (WIN - HOP));
+                    gc[st] = *reinterpret_cast<const f4v*>(p0 + 2 * (WIN - HOP));
+                    gd[st] = *reinterpret_cast<const f4v*>(p0 + 3 * (WIN - HOP));
+                }
+            }
+            store_tables();
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                const int i = 4 * (tid + GL_THREADS * st);
+                if (i < seg) *reinterpret_cast<f4v*>(yseg + i) = ((ga[st] + gb[st]) + gc[st]) + gd[st];
+            }
+        } else {
+            store_tables();
+#pragma unroll 2
+            for (int i = 4 * tid; i < seg; i += 4 * GL_THREADS) {
+                const int g = HOP * m0 + i;
+                const int q = g / HOP;
+                const int r = g - q * HOP;
+                float4 part[NOVER];
+#pragma unroll
+                for (int d = 0; d < NOVER; ++d) {
+                    const int m2 = q - (NOVER - 1) + d;
+                    const int mc = min(max(m2, 0), T - 1);
+                    part[d] = *reinterpret_cast<const float4*>(fu + (long)mc * WIN + r + HOP * (NOVER - 1 - d));
+                    if (m2 != mc) part[d] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                float4 acc = part[0];
+#pragma unroll
+                for (int d = 1; d < NOVER; ++d) {
+                    acc.x += part[d].x; acc.y += part[d].y; acc.z += part[d].z; acc.w += part[d].w;
+                }
+                *reinterpret_cast<float4*>(yseg + i) = acc;
+            }
+        }
+    }
+    GL_STAMP(2);
+    __syncthreads();
+    GL_STAMP(3);
+
+    typedef GL2Frame<WIN, HOP> Fr;
+    // (the twiddles of passes 2 and 3 are read from the LDS tables at each use: kept in registers for the whole kernel,
+    // 54 per lane, they push the two frames' working set over the 256-register budget - measured 12.3 ms for 60
+    // iterations at B = 32 with the pass-2 set resident and 40 registers spilled, 19.3 ms with both, 9.0 ms this way)
+    // ---- the stages of one frame: m* = arithmetic on registers, x* = the exchange (16 LDS writes, then the reads
+    // whose results the next m* stage needs)
+    auto s0_load = [&](Fr& f, int fi) {
+        f.ys = yseg + HOP * fi;
+        f.out = frames_out + (fb + m0 + fi) * WIN;
+    };
+    auto m1 = [&](Fr& f) {
+        // analysis window, even/odd packing z[c] = (y[2c], y[2c+1]), c = lane + 64 i: i <= 8 always inside the window,
+        // i = 9 for the first HALF - 576 lanes, i >= 10 never
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int c = lane + 64 * i;
+            const int cc = (i < 9 || c < HALF) ? c : 0;
+            const float2 sv = *reinterpret_cast<const float2*>(f.ys + 2 * cc);
+            const float2 wv = *reinterpret_cast<const float2*>(win_s + 2 * cc);
+            cplx z = {sv.x * wv.x, sv.y * wv.y};
+            if (i == 9 && c >= HALF) z = cplx{0.f, 0.f};
+            f.v[i] = z;
+        }
+        dft16_fwd_in10(f.v);
+    };
+    auto x_pass1 = [&](Fr& f) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) lds[fft_pad(16 * lane + c)] = f.v[c];
+        fft_load(f.v, lds, lane);
+    };
+    auto x_pass2 = [&](Fr& f) {
+        const int base = (lane >> 4) * 256 + (lane & 15);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) lds[fft_pad(base + 16 * c)] = f.v[c];
+        fft_load(f.v, lds, lane);
+    };
+    auto m2f = [&](Fr& f) {
+#pragma unroll
+        for (int i = 1; i < 16; ++i) f.v[i] = cmul_v(f.v[i], T2[(i - 1) * 16 + (lane & 15)]);
+        dft16<false>(f.v);
+    };
+    auto m2i = [&](Fr& f) {
+#pragma unroll
+        for (int i = 1; i < 16; ++i) f.v[i] = cmul_vc(f.v[i], T2[(i - 1) * 16 + (lane & 15)]);
+        dft16<true>(f.v);
+    };
+    auto m3 = [&](Fr& f) {                               // -> v[m] = Z[lane + 64 m]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int i = 1; i < 4; ++i) f.v[q + 4 * i] = cmul_v(f.v[q + 4 * i], T3[(i - 1) * 256 + lane + 64 * q]);
+            dft4<false>(f.v[q], f.v[q + 4], f.v[q + 8], f.v[q + 12]);
+        }
+        f.z512 = f.v[8];                                 // lane 0: Z[512]
+    };
+    auto x3 = [&](Fr& f) {
+        // upper half to LDS in natural order, then the partner bins 1024 - k of the pairs (k, 1024 - k),
+        // k = lane + 64 j, into v[8 + j]. Pair 0 of lane 0 is (0, 1024): its slot fft_pad(1024) is a dummy behind
+        // the buffer, Z[1024] = Z[0] is substituted in m4.
+#pragma unroll
+        for (int i = 8; i < 16; ++i) lds[fft_pad(lane + 64 * i)] = f.v[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f.v[8 + j] = lds[fft_pad(FFT_N - (lane + 64 * j))];
+    };
+    auto m4 = [&](Fr& f, const float (&mk)[8], const float (&mn)[8], float m512) {
+        // split -> re-phase against the target magnitude -> merge on the bin pairs; v[j] = Z'[k], v[8 + j] = Z'[1024 - k].
+        // The halvings of the split and of the merge (rfft_split, irfft_merge) are left out: the re-phasing divides by
+        // |X| anyway (2X against 2 max(1e-8, |X|) is the same quotient), and the merge's factor 1/2 goes into the
+        // 1/1024 of the inverse transform (m7). With T = W (Zk - conj Zn): 2 X[k] = E - i T, conj(2 X[1024-k]) = E + i T.
+        f.v[8] = lane == 0 ? f.v[0] : f.v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const cplx Wk = wk_s[lane + 64 * j];
+            const cplx cn = cconj(f.v[8 + j]);
+            const cplx E = cadd(f.v[j], cn);
+            const cplx Tt = cmul_v(csub(f.v[j], cn), Wk);
+            const cplx Xk = cadd_mi(E, Tt);               // 2 X[k]
+            const cplx Un = cadd_pi(E, Tt);               // conj(2 X[1024 - k])
+            const float ak = __builtin_fmaf(Xk.x, Xk.x, Xk.y * Xk.y), an = __builtin_fmaf(Un.x, Un.x, Un.y * Un.y);
+            const cplx Yk = Xk * (mk[j] * __builtin_amdgcn_rsqf(ak > 4e-16f ? ak : 4e-16f));      // Y[k]
+            const cplx Vn = Un * (mn[j] * __builtin_amdgcn_rsqf(an > 4e-16f ? an : 4e-16f));      // conj(Y[1024 - k])
+            const cplx E2 = cadd(Yk, Vn);
+            const cplx O2 = cmul_vc(csub(Yk, Vn), Wk);
+            f.v[j] = cadd_pi(E2, O2);                     // 2 Z'[k]
+            f.v[8 + j] = cconj(cadd_mi(E2, O2));          // 2 Z'[1024 - k]
+        }
+        // bin 512 pairs with itself: X512 = conj(Z512), Z'512 = conj(Y512); it is element 8 of lane 0
+        f.z512 = cconj(gl_rephase(cconj(f.z512), 2.f * m512));
+    };
+    auto x4 = [&](Fr& f) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lds[fft_pad(FFT_N - (lane + 64 * j))] = f.v[8 + j];   // (lane 0, j = 0: dummy slot)
+#pragma unroll
+        for (int i = 8; i < 16; ++i) f.v[i] = lds[fft_pad(lane + 64 * i)];
+    };
+    auto m5 = [&](Fr& f) {
+        f.v[8] = lane == 0 ? f.z512 : f.v[8];
+        dft16<true>(f.v);
+    };
+    auto m7 = [&](Fr& f, bool store) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int i = 1; i < 4; ++i) f.v[q + 4 * i] = cmul_vc(f.v[q + 4 * i], T3[(i - 1) * 256 + lane + 64 * q]);
+            dft4<true>(f.v[q], f.v[q + 4], f.v[q + 8], f.v[q + 12]);
+        }
+        const float sc = 0.5f / FFT_N;                   // (1/1024 of the inverse transform, 1/2 of the merge)
+        if (store) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int c = lane + 64 * i;
+                if (i < 9 || c < HALF) {
+                    const float2 wv = *reinterpret_cast<const float2*>(win_s + 2 * c);
+                    *reinterpret_cast<float2*>(f.out + 2 * c) = make_float2(f.v[i].x * sc * wv.x, f.v[i].y * sc * wv.y);
+                }
+            }
+        }
+    };
+
+    // frames of this wave: wave, wave + 4, ...; two at a time, half a stage apart: while one frame's exchange is in
+    // flight the other frame computes. A last, single frame runs as a pair with itself (the copy is not stored).
+    for (int fi = wave; fi < nfr; fi += 2 * GL_WAVES) {
+        Fr A, Bf;
+        const bool pair = fi + GL_WAVES < nfr;
+        s0_load(A, fi);
+        s0_load(Bf, pair ? fi + GL_WAVES : fi);
+        const int sb = 4 + 10 * (fi >= 2 * GL_WAVES);
+        (void)sb;
+        GL_STAMP(sb);
+        m1(A);   x_pass1(A);
+        m1(Bf);  GL2_LAND(A.v);  x_pass1(Bf);
+        GL_STAMP(sb + 1);
+        m2f(A);  GL2_LAND(Bf.v); x_pass2(A);
+        m2f(Bf); GL2_LAND(A.v);  x_pass2(Bf);
+        GL_STAMP(sb + 2);
+        m3(A);   GL2_LAND(Bf.v); x3(A);
+        m3(Bf);  GL2_LAND(A.v);  x3(Bf);
+        GL_STAMP(sb + 3);
+        const int fn = fi + 2 * GL_WAVES;               // the wave's next pair
+        m4(A, mkA, mnA, m512A);   GL2_LAND(Bf.v); x4(A);
+        if (fn < nfr) load_mag(mkA, mnA, m512A, fn);
+        m4(Bf, mkB, mnB, m512B);  GL2_LAND(A.v);  x4(Bf);
+        if (fn < nfr) load_mag(mkB, mnB, m512B, min(fn + GL_WAVES, nfr - 1));
+        GL_STAMP(sb + 4);
+        m5(A);   GL2_LAND(Bf.v); x_pass1(A);
+        m5(Bf);  GL2_LAND(A.v);  x_pass1(Bf);
+        GL_STAMP(sb + 5);
+        m2i(A);  GL2_LAND(Bf.v); x_pass2(A);
+        m2i(Bf); GL2_LAND(A.v);  x_pass2(Bf);
+        GL_STAMP(sb + 6);
+        m7(A, true);
+        GL2_LAND(Bf.v);
+        m7(Bf, pair);
+        GL_STAMP(sb + 7);
+    }
+}
+
 // More than the default 64 KB of dynamic LDS for gl_iter: the attribute is per device. Called at taco_create (so that
 // an entry point that must not do set-up work finds it done) and, idempotently, by every launch.
 void gl_prepare_device() {
@@ -307,8 +677,32 @@ void gl_prepare_device() {
                         gl_iter_kernel<true, 1200, 300>})
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter2_kernel<1200, 300>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set[dev] = true;
     }
+}
+
+#ifdef GL_STAMPS
+extern "C" int taco_debug_gl_stamps(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(gl_dbg), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
+
+// [window | T2, T3 (fft_tw_entry) | W[0..511]] as floats, the order gl_iter2_kernel carves its LDS in
+std::vector<float> gl_lds_image(const std::vector<float>& tw, const std::vector<float>& win) {
+    std::vector<float> img(win);
+    auto W = [&](int j) { return std::pair<float, float>(tw[2 * j], tw[2 * j + 1]); };
+    for (int e = 0; e < FFT_TW; ++e) {
+        int j;
+        if (e < FFT_T2) j = 8 * (e % 16) * (e / 16 + 1);
+        else { const int e2 = e - FFT_T2; j = 2 * (e2 % 256) * (e2 / 256 + 1); }
+        img.push_back(W(j).first);
+        img.push_back(W(j).second);
+    }
+    for (int j = 0; j < FFT_N / 2; ++j) { img.push_back(W(j).first); img.push_back(W(j).second); }
+    while (img.size() % 4) img.push_back(0.f);
+    return img;
 }
 
 void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, float* frames_out, int B, int T,
@@ -317,19 +711,31 @@ void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, f
     // frames per workgroup: as many as keep the y segment within ~24 KB of LDS (2 workgroups per CU and more)
     int run = GL_RUN;
     while (run > 1 && ((size_t)(run - 1) * p.hop + p.win) * 4 > 24 * 1024) --run;
-    // small jobs: shorter runs (down to one frame per wave) until the grid covers the chip twice; the overlap-add
-    // order per sample does not depend on the run length, so results are bit-identical
-    while (run > GL_WAVES && (long)B * ((T + run - 1) / run) < 512) run -= GL_WAVES;
+    const bool dflt = p.win == 1200 && p.hop == 300;
+    // the iteration of the TF flavour at the default geometry runs two frames per wave (gl_iter2_kernel); the choice
+    // depends on the geometry and the flavour only, never on the batch, so an utterance's result does not depend on
+    // what it is batched with
+    const bool two = dflt && !librosa && !first && run == GL_RUN && p.lds_image && !getenv("TACO_GL_ONE_FRAME");
+    // small jobs: shorter runs (down to one frame, or one pair of frames, per wave) until the grid covers the chip
+    // twice; the overlap-add order per sample does not depend on the run length, so results are bit-identical
+    const int min_run = two ? 2 * GL_WAVES : GL_WAVES;
+    while (run > min_run && (long)B * ((T + run - 1) / run) < 512) run -= GL_WAVES;
     const int runs_per_utt = (T + run - 1) / run;
-    const size_t lds = (size_t)((((run - 1) * p.hop + p.win + 3) & ~3) + ((p.win + 3) & ~3)) * 4 +
-                       (size_t)(FFT_TW + FFT_N / 2 + GL_WAVES * FFT_LDS) * sizeof(cplx);
     gl_prepare_device();
     const dim3 grid((unsigned)(B * runs_per_utt));
-    const bool dflt = p.win == 1200 && p.hop == 300;
-    auto* kern = librosa ? (dflt ? gl_iter_kernel<true, 1200, 300> : gl_iter_kernel<true, 0, 0>)
-                         : (dflt ? gl_iter_kernel<false, 1200, 300> : gl_iter_kernel<false, 0, 0>);
-    hipLaunchKernelGGL(kern, grid, dim3(GL_THREADS), lds, s, frames_in, mag, frames_out, (const float2*)p.twiddle,
-                       p.window, phase_u, B, T, p.hop, p.win, p.nbins, first, run, runs_per_utt);
+    if (two) {
+        const size_t lds = (size_t)(((run - 1) * p.hop + p.win + 3) & ~3) * 4 + (size_t)p.win * 4 +
+                           (size_t)(FFT_TW + FFT_N / 2 + GL_WAVES * GL2_LDS) * sizeof(cplx);
+        hipLaunchKernelGGL((gl_iter2_kernel<1200, 300>), grid, dim3(GL_THREADS), lds, s, frames_in, mag, frames_out,
+                           p.lds_image, B, T, p.nbins, run, runs_per_utt);
+    } else {
+        const size_t lds = (size_t)((((run - 1) * p.hop + p.win + 3) & ~3) + ((p.win + 3) & ~3)) * 4 +
+                           (size_t)(FFT_TW + FFT_N / 2 + GL_WAVES * FFT_LDS) * sizeof(cplx);
+        auto* kern = librosa ? (dflt ? gl_iter_kernel<true, 1200, 300> : gl_iter_kernel<true, 0, 0>)
+                             : (dflt ? gl_iter_kernel<false, 1200, 300> : gl_iter_kernel<false, 0, 0>);
+        hipLaunchKernelGGL(kern, grid, dim3(GL_THREADS), lds, s, frames_in, mag, frames_out, (const float2*)p.twiddle,
+                           p.window, phase_u, B, T, p.hop, p.win, p.nbins, first, run, runs_per_utt);
+    }
     if (tm) tm->end(KK_GL_ITER, s);
 }
 

@@ -152,6 +152,8 @@ struct GLPlan {
     int n_fft, hop, win, nbins;       // 2048, 300, 1200, 1025
     const float* twiddle;             // [n_fft] complex (cos, -sin)(2*pi*j/n_fft), float2
     const float* window;              // [win] periodic Hann
+    const float* lds_image;           // [win floats | FFT_TW + 512 complex]: window, pass-2/3 twiddles and split twiddles
+                                      //   exactly as gl_iter2 keeps them in LDS (built once at taco_create), or null
 };
 void launch_gl_mag(const float* lin, float* mag, size_t n, float min_db, float ref_db, float power,
                    hipStream_t s, Timing* tm);
@@ -160,6 +162,7 @@ void launch_gl_mag(const float* lin, float* mag, size_t n, float min_db, float r
 // exp(2 pi i phase_u), phase_u [B*T][nbins] or null = zero phase).
 void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, float* frames_out, int B, int T,
                     int first, hipStream_t s, Timing* tm, bool librosa = false, const float* phase_u = nullptr);
+std::vector<float> gl_lds_image(const std::vector<float>& twiddle, const std::vector<float>& window);
 void gl_prepare_device();   // per-device kernel attributes of gl_iter (idempotent)
 void launch_gl_ola(const GLPlan& p, const float* frames, float* wav, int B, int T, hipStream_t s, Timing* tm);
 // librosa.istft's output: wav [B][hop (T-1)], window-sum-square normalised, n_fft/2 trimmed from both ends
