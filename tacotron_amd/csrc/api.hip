@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -508,6 +509,19 @@ int run_cbhg(taco_ctx* c, const CbhgW& cb, const float* x, const int32_t* lens, 
                      nullptr, nullptr, 0, hwA, cb.highway_depth, ACT_NONE, 0};
         launch_conv_gemm(g, s, tm);
         h = hwA;
+    }
+    if (cb.highway_depth == 128 && cb.gru * 6 == 768 && cb.n_highway >= 0 && cb.n_highway <= 8 &&
+        !getenv("TACO_NO_CBHG_TAIL")) {
+        // highway layers + the BiGRU's hoisted input projections as one launch (cbhg_tail_kernel)
+        CbhgTailArgs t{};
+        t.X = h; t.ldx = cb.highway_depth; t.M = M;
+        for (int i = 0; i < cb.n_highway; ++i) { t.Whw[i] = cb.hw[i].W; t.bhw[i] = cb.hw[i].bias; }
+        t.n_hw = cb.n_highway;
+        t.Wr = cb.rnn_in.W; t.br = cb.rnn_in.bias; t.ldwr = cb.rnn_in.ldw; t.Nr = cb.rnn_in.N;
+        t.out = xp; t.ldo = 6 * cb.gru;
+        launch_cbhg_tail(t, s, tm);
+        launch_bigru_scan(xp, cb.Pg, cb.Pc, lens, out, B, T, s, tm);
+        return 0;
     }
     // highway layers (modules.py:87-88,100-123)
     for (int i = 0; i < cb.n_highway; ++i) {

@@ -315,6 +315,170 @@ void launch_conv_gemm(const GemmArgs& a_in, hipStream_t s, Timing* tm) {
 }
 
 // ---------------------------------------------------------------------------------------
+// cbhg_tail: highway x n_hw + BiGRU input projections in one launch (kernels.h). BM rows per workgroup; the four waves
+// split the 256 output columns of a layer (64 each = one [32 H | 32 T] block, so a lane holds H and T of its unit), every
+// wave takes all BM rows. The activations [BM][128] stay in LDS (row stride 132: the 16 rows of a ds_read_b128 group
+// fall on 16 different bank quads) and are the A operand of every layer; the weights stream through a double-buffered
+// [16][256] LDS tile exactly as conv_gemm's B operand does, one continuous pipeline over all layers (the first chunk of
+// a layer is in flight under the last MFMAs of the layer before). k order within a chunk as in conv_gemm (lane half lk
+// feeds k = 8 lk + kk to MFMA kk), so a row's sums do not depend on BM: any tile choice gives the same bits.
+template <int BM>
+__global__ __launch_bounds__(256, 2) void cbhg_tail_kernel(CbhgTailArgs a) {
+    constexpr int D = 128, BK = 16, XS = D + 4, BN = 256, PAD = 4, TM = BM / 32, NKT = D / BK, NB = BK * BN / 4 / 256;
+    extern __shared__ __attribute__((aligned(16))) float tail_smem[];
+    float (*xs)[XS] = reinterpret_cast<float (*)[XS]>(tail_smem);
+    float (*Bs)[BK][BN + PAD] = reinterpret_cast<float (*)[BK][BN + PAD]>(tail_smem + BM * XS);
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lk = lane >> 5, li = lane & 31;
+    const int m0 = blockIdx.x * BM, wn = 64 * wave;
+
+    // "layers": n_hw highway layers, then Nr / 256 column chunks of the input projection
+    const int nrc = (a.Nr + BN - 1) / BN;
+    const int nl = a.n_hw + nrc;
+    auto layer_w = [&](int L, int& ldw) -> const float* {
+        if (L < a.n_hw) { ldw = BN; return a.Whw[L]; }
+        ldw = a.ldwr;
+        return a.Wr + (L - a.n_hw) * BN;
+    };
+    // weight chunks are fetched TWO chunks ahead (two register sets, even / odd chunks): with one workgroup's 16 MFMAs
+    // per chunk (BM = 32) a single chunk of run-ahead does not cover an L2 round trip
+    const int nchunks = nl * NKT;
+    f32x4v rbA[NB], rbB[NB];
+    auto fetch = [&](f32x4v (&rb)[NB], int c) {
+        if (c >= nchunks) return;
+        int ldw;
+        const float* W = layer_w(c / NKT, ldw);
+        const int kt = c % NKT;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = tid + 256 * i;
+            const int k = f / (BN / 4), nq = f % (BN / 4);
+            rb[i] = *reinterpret_cast<const f32x4v*>(W + (size_t)(kt * BK + k) * ldw + 4 * nq);
+        }
+    };
+    auto stash = [&](const f32x4v (&rb)[NB], int buf) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = tid + 256 * i;
+            const int k = f / (BN / 4), nq = f % (BN / 4);
+            *reinterpret_cast<f32x4v*>(&Bs[buf][k][4 * nq]) = rb[i];
+        }
+    };
+    fetch(rbA, 0);
+    fetch(rbB, 1);
+    // the rows' activations (zero rows past M)
+    for (int f = tid; f < BM * (D / 4); f += 256) {
+        const int row = f / (D / 4), c4 = f % (D / 4);
+        const int m = m0 + row;
+        f32x4v v = {0.f, 0.f, 0.f, 0.f};
+        if (m < a.M) v = *reinterpret_cast<const f32x4v*>(a.X + (size_t)m * a.ldx + 4 * c4);
+        *reinterpret_cast<f32x4v*>(&xs[row][4 * c4]) = v;
+    }
+    stash(rbA, 0);
+    __syncthreads();
+    fetch(rbA, 2);
+    for (int L = 0; L < nl; ++L) {
+        f32x16 acc[TM][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        auto compute = [&](int kt, int buf) {
+            float af[BK / 2][TM], bf[BK / 2][2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const f32x4v a0 = *reinterpret_cast<const f32x4v*>(&xs[32 * i + li][BK * kt + 8 * lk]);
+                const f32x4v a1 = *reinterpret_cast<const f32x4v*>(&xs[32 * i + li][BK * kt + 8 * lk + 4]);
+                af[0][i] = a0.x; af[1][i] = a0.y; af[2][i] = a0.z; af[3][i] = a0.w;
+                af[4][i] = a1.x; af[5][i] = a1.y; af[6][i] = a1.z; af[7][i] = a1.w;
+            }
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[kk][j] = Bs[buf][8 * lk + kk][wn + 32 * j + li];
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
+        };
+        static_assert(NKT % 2 == 0, "the chunk loop is unrolled by two");
+        for (int kt = 0; kt < NKT; kt += 2) {
+            const int c = L * NKT + kt;          // even chunk: lives in Bs[0], the next (odd) one in rbB
+            compute(kt, 0);
+            stash(rbB, 1);
+            __syncthreads();
+            fetch(rbB, c + 3);
+            compute(kt + 1, 1);
+            if (c + 2 < nchunks) stash(rbA, 0);
+            __syncthreads();
+            fetch(rbA, c + 4);
+        }
+        if (L < a.n_hw) {
+            // highway (modules.py:100-123): y = relu(H) * sigmoid(T) + x * (1 - sigmoid(T)), back into the LDS tile.
+            // Every wave is past the barrier that follows the layer's last MFMAs: nobody reads the old x any more.
+            const float* bias = a.bhw[L];
+            const float bh = bias[wn + li], bt = bias[wn + 32 + li];
+            const int unit = wn / 2 + li;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    const float hh = fmaxf(acc[i][0][r] + bh, 0.f);
+                    const float tt = 1.f / (1.f + expf(-(acc[i][1][r] + bt)));
+                    const float x = xs[row][unit];
+                    xs[row][unit] = hh * tt + x * (1.f - tt);
+                }
+            }
+            __syncthreads();
+        } else {
+            const int nc = (L - a.n_hw) * BN;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = nc + wn + 32 * j + li;
+                if (n >= a.Nr) continue;
+                const float bv = a.br ? a.br[n] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                        if (m < a.M) a.out[(size_t)m * a.ldo + n] = acc[i][j][r] + bv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+void launch_cbhg_tail(const CbhgTailArgs& a, hipStream_t s, Timing* tm) {
+    if (tm) tm->begin(KK_CONV_GEMM, s);
+    static bool attr_set[64] = {};   // more than the default 64 KB of dynamic LDS: the attribute is per device
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cbhg_tail_kernel<32>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cbhg_tail_kernel<64>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set[dev] = true;
+    }
+    // rows per workgroup: 64 when that still gives a workgroup per CU and more, else 32 (any choice gives the same bits)
+    const bool big = (a.M + 63) / 64 >= 256;
+    const int bm = big ? 64 : 32;
+    const size_t lds = ((size_t)bm * 132 + 2 * 16 * 260) * sizeof(float);
+    const dim3 grid((a.M + bm - 1) / bm);
+    if (big) hipLaunchKernelGGL((cbhg_tail_kernel<64>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((cbhg_tail_kernel<32>), grid, dim3(256), lds, s, a);
+    if (tm) tm->end(KK_CONV_GEMM, s);
+}
+
+// ---------------------------------------------------------------------------------------
 __global__ void embed_gather_kernel(const int32_t* __restrict__ ids, const float4* __restrict__ lut,
                                     float4* __restrict__ out, long n4, int wq, int num_rows) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {

@@ -68,6 +68,18 @@ struct GemmArgs {
     float p0, p1;                 // activation parameters (ACT_DB_NORM)
 };
 int conv_gemm_pick_splitk(int M, int N, int nk);
+
+// The tail of a CBHG as ONE launch (model/modules.py:87-98 up to the scan): n_hw highway layers of depth 128 followed by
+// the hoisted input projections of the BiGRU, xp = y @ Wr + br (N = 768). A workgroup keeps its rows' activations in LDS
+// from layer to layer; only the weights stream. Same arithmetic per row as the per-layer conv_gemm launches it replaces.
+struct CbhgTailArgs {
+    const float* X; int ldx;          // [M, 128] highway input
+    int M;
+    const float* Whw[8]; const float* bhw[8]; int n_hw;   // [128, 256] in the [32 H | 32 T] column blocks, bias [256]
+    const float* Wr; const float* br; int ldwr, Nr;       // [128, ldwr >= Nr], Nr = 768
+    float* out; int ldo;              // [M, Nr]
+};
+void launch_cbhg_tail(const CbhgTailArgs& a, hipStream_t s, Timing* tm);
 void launch_conv_gemm(const GemmArgs& a, hipStream_t s, Timing* tm);
 
 // out[m, :] = lut[clamp(ids[m]), :]  (width floats, multiple of 4)
