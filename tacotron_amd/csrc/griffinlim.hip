@@ -405,8 +405,15 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     cplx* lds = fft_s + wave * GL2_LDS;
 
-    const int b = blockIdx.x / runs_per_utt;
-    const int m0 = (blockIdx.x - b * runs_per_utt) * run;
+    // Workgroup i is placed on XCD i % 8: the runs are dealt out so that the workgroups of one XCD hold a contiguous
+    // range of runs, and neighbouring runs (which read three frames of each other's range) meet in that XCD's L2.
+    int wg = blockIdx.x;
+    {
+        const int per = gridDim.x >> 3, rem = gridDim.x & 7, x = wg & 7;
+        wg = x * per + min(x, rem) + (wg >> 3);
+    }
+    const int b = wg / runs_per_utt;
+    const int m0 = (wg - b * runs_per_utt) * run;
     const int nfr = min(run, T - m0);
     const long fb = (long)b * T;
     typedef float f4v __attribute__((ext_vector_type(4)));
@@ -520,7 +527,25 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
         f.ys = yseg + HOP * fi;
         f.out = frames_out + (fb + m0 + fi) * WIN;
     };
-    auto m1 = [&](Fr& f) {
+    // Table values (twiddles) of the next stage are read into tw[] for both frames of a pair at once, at a point where
+    // the only LDS reads in flight are older ones: LDS returns in order, so a table read issued behind the other
+    // frame's exchange could only be used after that exchange had landed, which is the wait the pairing is there to hide.
+    cplx tw[15];
+    auto ld_T2 = [&]() {
+#pragma unroll
+        for (int i = 0; i < 15; ++i) tw[i] = T2[i * 16 + (lane & 15)];
+    };
+    auto ld_T3 = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tw[3 * q + i] = T3[i * 256 + lane + 64 * q];
+    };
+    auto ld_wk = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tw[j] = wk_s[lane + 64 * j];
+    };
+    auto a1 = [&](Fr& f) {
         // analysis window, even/odd packing z[c] = (y[2c], y[2c+1]), c = lane + 64 i: i <= 8 always inside the window,
         // i = 9 for the first HALF - 576 lanes, i >= 10 never
 #pragma unroll
@@ -533,8 +558,8 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
             if (i == 9 && c >= HALF) z = cplx{0.f, 0.f};
             f.v[i] = z;
         }
-        dft16_fwd_in10(f.v);
     };
+    auto d1 = [&](Fr& f) { dft16_fwd_in10(f.v); };
     auto x_pass1 = [&](Fr& f) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) lds[fft_pad(16 * lane + c)] = f.v[c];
@@ -548,19 +573,17 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
     };
     auto m2f = [&](Fr& f) {
 #pragma unroll
-        for (int i = 1; i < 16; ++i) f.v[i] = cmul_v(f.v[i], T2[(i - 1) * 16 + (lane & 15)]);
-        dft16<false>(f.v);
+        for (int i = 1; i < 16; ++i) f.v[i] = cmul_v(f.v[i], tw[i - 1]);
     };
     auto m2i = [&](Fr& f) {
 #pragma unroll
-        for (int i = 1; i < 16; ++i) f.v[i] = cmul_vc(f.v[i], T2[(i - 1) * 16 + (lane & 15)]);
-        dft16<true>(f.v);
+        for (int i = 1; i < 16; ++i) f.v[i] = cmul_vc(f.v[i], tw[i - 1]);
     };
     auto m3 = [&](Fr& f) {                               // -> v[m] = Z[lane + 64 m]
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
-            for (int i = 1; i < 4; ++i) f.v[q + 4 * i] = cmul_v(f.v[q + 4 * i], T3[(i - 1) * 256 + lane + 64 * q]);
+            for (int i = 1; i < 4; ++i) f.v[q + 4 * i] = cmul_v(f.v[q + 4 * i], tw[3 * q + i - 1]);
             dft4<false>(f.v[q], f.v[q + 4], f.v[q + 8], f.v[q + 12]);
         }
         f.z512 = f.v[8];                                 // lane 0: Z[512]
@@ -582,7 +605,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
         f.v[8] = lane == 0 ? f.v[0] : f.v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const cplx Wk = wk_s[lane + 64 * j];
+            const cplx Wk = tw[j];
             const cplx cn = cconj(f.v[8 + j]);
             const cplx E = cadd(f.v[j], cn);
             const cplx Tt = cmul_v(csub(f.v[j], cn), Wk);
@@ -613,7 +636,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
-            for (int i = 1; i < 4; ++i) f.v[q + 4 * i] = cmul_vc(f.v[q + 4 * i], T3[(i - 1) * 256 + lane + 64 * q]);
+            for (int i = 1; i < 4; ++i) f.v[q + 4 * i] = cmul_vc(f.v[q + 4 * i], tw[3 * q + i - 1]);
             dft4<true>(f.v[q], f.v[q + 4], f.v[q + 8], f.v[q + 12]);
         }
         const float sc = 0.5f / FFT_N;                   // (1/1024 of the inverse transform, 1/2 of the merge)
@@ -639,14 +662,15 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
         const int sb = 4 + 10 * (fi >= 2 * GL_WAVES);
         (void)sb;
         GL_STAMP(sb);
-        m1(A);   x_pass1(A);
-        m1(Bf);  GL2_LAND(A.v);  x_pass1(Bf);
+        a1(A);   a1(Bf);
+        d1(A);   x_pass1(A);  ld_T2();
+        d1(Bf);  GL2_LAND(A.v);  x_pass1(Bf);
         GL_STAMP(sb + 1);
-        m2f(A);  GL2_LAND(Bf.v); x_pass2(A);
-        m2f(Bf); GL2_LAND(A.v);  x_pass2(Bf);
+        m2f(A);  dft16<false>(A.v);  GL2_LAND(Bf.v); x_pass2(A);
+        m2f(Bf); ld_T3(); dft16<false>(Bf.v); GL2_LAND(A.v);  x_pass2(Bf);
         GL_STAMP(sb + 2);
         m3(A);   GL2_LAND(Bf.v); x3(A);
-        m3(Bf);  GL2_LAND(A.v);  x3(Bf);
+        m3(Bf);  ld_wk(); GL2_LAND(A.v);  x3(Bf);
         GL_STAMP(sb + 3);
         const int fn = fi + 2 * GL_WAVES;               // the wave's next pair
         m4(A, mkA, mnA, m512A);   GL2_LAND(Bf.v); x4(A);
@@ -654,11 +678,11 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
         m4(Bf, mkB, mnB, m512B);  GL2_LAND(A.v);  x4(Bf);
         if (fn < nfr) load_mag(mkB, mnB, m512B, min(fn + GL_WAVES, nfr - 1));
         GL_STAMP(sb + 4);
-        m5(A);   GL2_LAND(Bf.v); x_pass1(A);
+        m5(A);   GL2_LAND(Bf.v); x_pass1(A);  ld_T2();
         m5(Bf);  GL2_LAND(A.v);  x_pass1(Bf);
         GL_STAMP(sb + 5);
-        m2i(A);  GL2_LAND(Bf.v); x_pass2(A);
-        m2i(Bf); GL2_LAND(A.v);  x_pass2(Bf);
+        m2i(A);  dft16<true>(A.v);  GL2_LAND(Bf.v); x_pass2(A);
+        m2i(Bf); ld_T3(); dft16<true>(Bf.v); GL2_LAND(A.v);  x_pass2(Bf);
         GL_STAMP(sb + 6);
         m7(A, true);
         GL2_LAND(Bf.v);
@@ -718,8 +742,16 @@ void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, f
     const bool two = dflt && !librosa && !first && run == GL_RUN && p.lds_image && !getenv("TACO_GL_ONE_FRAME");
     // small jobs: shorter runs (down to one frame, or one pair of frames, per wave) until the grid covers the chip
     // twice; the overlap-add order per sample does not depend on the run length, so results are bit-identical
-    const int min_run = two ? 2 * GL_WAVES : GL_WAVES;
-    while (run > min_run && (long)B * ((T + run - 1) / run) < 512) run -= GL_WAVES;
+    if (two) {
+        // whole pairs per wave only (8 or 16 frames); the shorter run when it does not cost another round of
+        // workgroups over the chip's 512 places (two per CU): a workgroup lives for about one gather plus one
+        // transform time per pair, and a gather takes about as long as a pair
+        const long slots = 512;
+        auto rounds = [&](int r) { return ((long)B * ((T + r - 1) / r) + slots - 1) / slots; };
+        if (rounds(8) * 2 <= rounds(16) * 3) run = 8;
+    } else {
+        while (run > GL_WAVES && (long)B * ((T + run - 1) / run) < 512) run -= GL_WAVES;
+    }
     const int runs_per_utt = (T + run - 1) / run;
     gl_prepare_device();
     const dim3 grid((unsigned)(B * runs_per_utt));
