@@ -293,7 +293,11 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
     float* keys_s = wsum_s + 8;                                          // [Tp][256] when staged
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bt = blockIdx.x >> 5, j = blockIdx.x & 31;
+    // (placement experiment, TACO_PD_XCD_PACK: a one-tile launch of 256 workgroups of which only those dealt to one XCD,
+    // every eighth, take a role; the hand-offs are placement-independent either way)
+    if (a.xcd_pack && (blockIdx.x & 7)) return;
+    const int wid = a.xcd_pack ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int bt = wid >> 5, j = wid & 31;
 #ifdef PD_PHASE_STAMPS   // diagnostic build: when did workgroup 0 start, finish step 0 (everybody resident), finish
     if (blockIdx.x == 0 && tid == 0) reinterpret_cast<unsigned long long*>(a.sync)[8] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -779,7 +783,9 @@ int launch_dec_persistent(DecPersistArgs a, hipStream_t s, Timing* tm) {
     }
     const size_t lds = dec_persistent_lds_bytes(a.T_in, a.B, &a.lds_keys, &a.lds_vals);
     if (tm) tm->begin(KK_DEC_PERSIST, s);
-    hipLaunchKernelGGL(dec_persistent_kernel, dim3(32 * (a.Bpad / 16)), dim3(PD_THREADS), lds, s, a);
+    static const bool pack_env = getenv("TACO_PD_XCD_PACK") != nullptr;
+    a.xcd_pack = pack_env && a.Bpad == 16;
+    hipLaunchKernelGGL(dec_persistent_kernel, dim3(a.xcd_pack ? 256 : 32 * (a.Bpad / 16)), dim3(PD_THREADS), lds, s, a);
     if (tm) tm->end(KK_DEC_PERSIST, s);
     return 0;
 }

@@ -13,6 +13,7 @@
 // one conflict-free ds_read_b32 per fragment (lane l: B[k][n = l & 31]).
 // Global->register prefetch of tile k+1 overlaps the MFMAs of tile k (one barrier per tile).
 #include "kernels.h"
+#include <cstring>
 
 namespace taco {
 
@@ -298,7 +299,19 @@ void launch_conv_gemm(const GemmArgs& a_in, hipStream_t s, Timing* tm) {
     const int z = a.splitk > 1 ? a.splitk : groups;
     // tile choice: big tiles when one slice alone still gives ~a block per CU, else 64x64
     const long blocks128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if ((blocks128 >= 192 && a.N >= 128 && a.splitk == 1) || a.act == ACT_HIGHWAY_FUSED) {
+    static const char* tile_env = getenv("TACO_GEMM_TILE");     // (experiments: 64x128 or 128x64 for the big-tile cases)
+    const bool big = (blocks128 >= 192 && a.N >= 128 && a.splitk == 1) || a.act == ACT_HIGHWAY_FUSED;
+    if (big && tile_env && !strcmp(tile_env, "64x128")) {
+        dim3 grid((a.N + 127) / 128, (a.M + 63) / 64, z);
+        hipLaunchKernelGGL((conv_gemm_kernel<64, 128>), grid, dim3(256), 0, s, a);
+    } else if (big && a.act != ACT_HIGHWAY_FUSED && (tile_env ? !strcmp(tile_env, "128x64")
+                                                              : (a.N <= 128 || (a.N % 128 != 0 && a.N % 128 <= 64)))) {
+        // half-width tiles where a 128-wide one would be the only one of its row block (N = 128: twice the workgroups
+        // per CU, measured 60 against 71 us at M = 32000, K = 640) or mostly padding (N = 1025: 180 against 196 us);
+        // the k order of an element's sum is the same for every tile shape, so the choice does not change a bit
+        dim3 grid((a.N + 63) / 64, (a.M + 127) / 128, z);
+        hipLaunchKernelGGL((conv_gemm_kernel<128, 64>), grid, dim3(256), 0, s, a);
+    } else if (big) {
         dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, z);
         hipLaunchKernelGGL((conv_gemm_kernel<128, 128>), grid, dim3(256), 0, s, a);
     } else {

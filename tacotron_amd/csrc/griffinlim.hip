@@ -477,10 +477,15 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
                 if (i < seg) {
                     const int qq = i / HOP;
                     const float* p0 = base + qq * (WIN - HOP) + i;        // = base + qq*WIN + (i - qq*HOP)
+#ifdef GL_EXP_NO_GATHER
+                    ga[st] = gb[st] = gc[st] = gd[st] = f4v{1e-3f * (float)i, 0.f, 1e-3f, 0.f};
+                    (void)p0;
+#else
                     ga[st] = *reinterpret_cast<const f4v*>(p0);
                     gb[st] = *reinterpret_cast<const f4v*>(p0 + (WIN - HOP));
                     gc[st] = *reinterpret_cast<const f4v*>(p0 + 2 * (WIN - HOP));
                     gd[st] = *reinterpret_cast<const f4v*>(p0 + 3 * (WIN - HOP));
+#endif
                 }
             }
             store_tables();

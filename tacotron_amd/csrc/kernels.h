@@ -151,6 +151,7 @@ struct DecPersistArgs {
     int B, Bpad, T_in, S;
     int lds_keys, lds_vals;   // filled by the launcher: key rows per attention part staged in LDS, values staged or not
     unsigned long long* dbg;  // diagnostic builds (-DPD_STAMPS): s_memrealtime stamps of workgroup 0, step 5
+    int xcd_pack;             // placement experiment (launcher, TACO_PD_XCD_PACK): see dec_persistent_kernel
 };
 int launch_dec_persistent(DecPersistArgs a, hipStream_t s, Timing* tm);
 // Status words of a handle's persistent decodes, as unsigned indices into DecPersistArgs::sync. [0, 32) are per launch
