@@ -159,6 +159,33 @@ def main():
     ap.add_argument('--keep-hw-queues', action='store_true', help='do not raise GPU_MAX_HW_QUEUES to 8')
     args = ap.parse_args()
 
+    inherited_leg = None
+    if (int(os.environ.get('RANK', 0)) == 0 and int(os.environ.get('WORLD_SIZE', 1)) == 1 and not args.no_extras and not args.keep_hw_queues and
+            os.environ.get('GPU_MAX_HW_QUEUES') != HWQ_INHERITED):
+        # The same headline leg at the hardware-queue count this process inherited (the GPU box exports 4), in a child
+        # process that runs to its end BEFORE this process touches the GPU: a process that has initialised the GPU
+        # must not start (fork + exec) another program on this pool.
+        env = dict(os.environ)
+        if HWQ_INHERITED is None:
+            env.pop('GPU_MAX_HW_QUEUES', None)
+        else:
+            env['GPU_MAX_HW_QUEUES'] = HWQ_INHERITED
+        cmd = [sys.executable, os.path.abspath(__file__), '--keep-hw-queues', '--no-extras', '--no-roofline',
+               '--no-cpu-baseline', '--steps', str(args.steps), '--warmup', str(args.warmup), '--batch', str(args.batch),
+               '--t-in', str(args.t_in), '--max-iters', str(args.max_iters), '--streams', str(max(1, args.streams)),
+               '--decode-mode', str(args.decode_mode)] + (['--to-wav'] if args.to_wav else [])
+        cp = None
+        try:
+            cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+            line = [l for l in cp.stdout.splitlines() if l.startswith('{')][-1]
+            child = json.loads(line)
+            inherited_leg = {'value': child['value'], 'ms_per_step': child['ms_per_step'],
+                             'gpu_max_hw_queues': HWQ_INHERITED}
+        except Exception as ex:                    # reported, never fatal for the headline line
+            inherited_leg = {'error': repr(ex)[:200], 'rc': cp.returncode if cp is not None else None,
+                             'stdout_tail': (cp.stdout[-300:] if cp is not None else None),
+                             'stderr_tail': (cp.stderr[-400:] if cp is not None else None)}
+
     import torch
     import torch.distributed as dist
     from tacotron_amd.engine import TacoEngine
@@ -382,30 +409,8 @@ def main():
         dist.destroy_process_group()
     for e in engines:
         e.close()
-    if (rank == 0 and world == 1 and not args.no_extras and not args.keep_hw_queues and
-            os.environ.get('GPU_MAX_HW_QUEUES') != HWQ_INHERITED):
-        # the same headline leg at the hardware-queue count this process inherited (the GPU box exports 4)
-        env = dict(os.environ)
-        if HWQ_INHERITED is None:
-            env.pop('GPU_MAX_HW_QUEUES', None)
-        else:
-            env['GPU_MAX_HW_QUEUES'] = HWQ_INHERITED
-        cmd = [sys.executable, os.path.abspath(__file__), '--keep-hw-queues', '--no-extras', '--no-roofline',
-               '--no-cpu-baseline', '--steps', str(args.steps), '--warmup', str(args.warmup), '--batch', str(B),
-               '--t-in', str(T_in), '--max-iters', str(S), '--streams', str(len(engines)),
-               '--decode-mode', str(args.decode_mode)] + (['--to-wav'] if args.to_wav else [])
-        cp = None
-        try:
-            cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
-            line = [l for l in cp.stdout.splitlines() if l.startswith('{')][-1]
-            child = json.loads(line)
-            res['value_at_inherited_hw_queues'] = {'value': child['value'], 'ms_per_step': child['ms_per_step'],
-                                                   'gpu_max_hw_queues': HWQ_INHERITED}
-        except Exception as ex:                    # reported, never fatal for the headline line
-            res['value_at_inherited_hw_queues'] = {
-                'error': repr(ex)[:200], 'rc': cp.returncode if cp is not None else None,
-                'stdout_tail': (cp.stdout[-300:] if cp is not None else None),
-                'stderr_tail': (cp.stderr[-400:] if cp is not None else None)}
+    if rank == 0 and inherited_leg is not None:
+        res['value_at_inherited_hw_queues'] = inherited_leg
     if rank == 0:
         print(json.dumps(res))
 

@@ -45,8 +45,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    // Tile of this workgroup. The hardware deals workgroups to the 8 XCDs round-robin by linear id: id = 8 l + xcd.
+    // All column tiles of a row block get consecutive l on ONE XCD (they read the same A rows: the second to last of
+    // them find the rows in that XCD's L2 instead of fetching them again from memory), row blocks go round the XCDs.
+    const int nx = (a.N + BN - 1) / BN;
+    int m0, n0;
+    {
+        const int id = blockIdx.x, xcd = id & 7, l = id >> 3;
+        const int yy = l / nx;
+        n0 = (l - yy * nx) * BN;
+        m0 = (yy * 8 + xcd) * BM;
+        if (m0 >= a.M) return;                    // (grid rounded up to whole rounds of 8 row blocks)
+    }
     const int wm = (wave >> 1) * WM;
     const int wn = (wave & 1) * WN;
 
@@ -63,6 +73,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
         taps = g.taps; padl = g.padl;
         C += g.coff;
     }
+    // k-tile order: channel block outer, tap inner, so that the `taps` shifted reads of the same A rows follow each
+    // other (L1/L2 hits) instead of coming Cin/16 tiles apart, which for the projection convolutions (Cin = 1024,
+    // 2048) is past any cache: k-tile kt covers channels 16 (kt / taps) .. +15 of tap kt % taps.
     // split-K: grid.z slices of the k-tile range, raw partial sums out (splitk_epilogue_kernel finishes)
     const int nk_all = taps * a.Cin / BK;
     int kt0 = 0, kt1 = nk_all;
@@ -92,10 +105,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     for (int i = 0; i < NB; ++i) {
         const int f = tid + 256 * i;
         const int k = f / (BN / 4), nq = f % (BN / 4);
-        wp[i] = W + (size_t)(kt0 * BK + k) * a.ldw + n0 + 4 * nq;
+        wp[i] = W + (size_t)k * a.ldw + n0 + 4 * nq;
     }
-    const size_t wstep = (size_t)BK * a.ldw;
-    int tap = (kt0 * BK) / a.Cin, c0 = (kt0 * BK) % a.Cin;     // position of the NEXT tile to fetch
+    int tap = kt0 % taps, c0 = (kt0 / taps) * BK;              // position of the NEXT tile to fetch
     const unsigned ldx4 = (unsigned)a.ldx * 4u;
 
     typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -114,12 +126,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
                 rp[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xr, vo2, 0, 0)); \
             }                                                                                            \
         }                                                                                                \
-        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                 \
-            rb[i] = *reinterpret_cast<const f32x4v*>(wp[i]);                                             \
-            wp[i] += wstep;                                                                              \
-        }                                                                                                \
-        c0 += BK;                                                                                        \
-        if (c0 == a.Cin) { c0 = 0; ++tap; }                                                              \
+        const size_t wrow = (size_t)(tap * a.Cin + c0) * a.ldw;                                          \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                   \
+            rb[i] = *reinterpret_cast<const f32x4v*>(wp[i] + wrow);                                      \
+        ++tap;                                                                                           \
+        if (tap == taps) { tap = 0; c0 += BK; }                                                          \
     } while (0)
 #define CG_STASH(buf)                                                                                    \
     do {                                                                                                 \
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
 
     // epilogue: lane holds column n = ..+(lane&31); rows (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (a.splitk > 1) {
-        const int ldp = gridDim.x * BN;
+        const int ldp = nx * BN;
         float* P = a.partial + (size_t)blockIdx.z * a.M * ldp;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -291,6 +302,12 @@ int conv_gemm_pick_splitk(int M, int N, int nk) {
     return std::min(8, nk / 64);
 }
 
+// 1-D grid over (row blocks rounded up to a multiple of 8) x column tiles: the kernel derives its tile from the id
+static dim3 cg_grid(const GemmArgs& a, int bm, int bn, int z) {
+    const int nx = (a.N + bn - 1) / bn, ny = (a.M + bm - 1) / bm;
+    return dim3((unsigned)(nx * 8 * ((ny + 7) / 8)), 1, (unsigned)z);
+}
+
 void launch_conv_gemm(const GemmArgs& a_in, hipStream_t s, Timing* tm) {
     GemmArgs a = a_in;
     if (tm) tm->begin(KK_CONV_GEMM, s);
@@ -302,23 +319,19 @@ void launch_conv_gemm(const GemmArgs& a_in, hipStream_t s, Timing* tm) {
     static const char* tile_env = getenv("TACO_GEMM_TILE");     // (experiments: 64x128 or 128x64 for the big-tile cases)
     const bool big = (blocks128 >= 192 && a.N >= 128 && a.splitk == 1) || a.act == ACT_HIGHWAY_FUSED;
     if (big && tile_env && !strcmp(tile_env, "64x128")) {
-        dim3 grid((a.N + 127) / 128, (a.M + 63) / 64, z);
-        hipLaunchKernelGGL((conv_gemm_kernel<64, 128>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_gemm_kernel<64, 128>), cg_grid(a, 64, 128, z), dim3(256), 0, s, a);
     } else if (big && a.act != ACT_HIGHWAY_FUSED && (tile_env ? !strcmp(tile_env, "128x64")
                                                               : (a.N <= 128 || (a.N % 128 != 0 && a.N % 128 <= 64)))) {
         // half-width tiles where a 128-wide one would be the only one of its row block (N = 128: twice the workgroups
         // per CU, measured 60 against 71 us at M = 32000, K = 640) or mostly padding (N = 1025: 180 against 196 us);
         // the k order of an element's sum is the same for every tile shape, so the choice does not change a bit
-        dim3 grid((a.N + 63) / 64, (a.M + 127) / 128, z);
-        hipLaunchKernelGGL((conv_gemm_kernel<128, 64>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_gemm_kernel<128, 64>), cg_grid(a, 128, 64, z), dim3(256), 0, s, a);
     } else if (big) {
-        dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, z);
-        hipLaunchKernelGGL((conv_gemm_kernel<128, 128>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_gemm_kernel<128, 128>), cg_grid(a, 128, 128, z), dim3(256), 0, s, a);
     } else {
-        dim3 grid((a.N + 63) / 64, (a.M + 63) / 64, z);
-        hipLaunchKernelGGL((conv_gemm_kernel<64, 64>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_gemm_kernel<64, 64>), cg_grid(a, 64, 64, z), dim3(256), 0, s, a);
         if (a.splitk > 1) {
-            const int ldp = grid.x * 64;
+            const int ldp = (a.N + 63) / 64 * 64;
             long n4 = (long)a.M * (ldp / 4);
             int blocks = (int)std::min<long>((n4 + 255) / 256, 2048);
             hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, a, ldp);
