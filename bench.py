@@ -379,12 +379,11 @@ def main():
         solo_us = 1e6 * sec
         if dom == loop_fam and live_n:
             sec = live_ms * 1e-3 / live_n          # average over the launches of the timed region
-        traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
-            traffic = tj.get('B%d_Tin%d_S%d' % (B, T_in, S), {}).get(dom, {}).get('bytes_per_launch')
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json'))).get('B%d_Tin%d_S%d' % (B, T_in, S), {})
         except Exception:
-            traffic = None
+            tj = {}
+        traffic = tj.get(dom, {}).get('bytes_per_launch')
         r0 = roof(dom, sec, leaf[dom]['launches'])
         r0.update({'traffic': traffic, 'avg_launch_us_one_batch_in_flight': solo_us,
                    'launches_timed': live_n if dom == loop_fam and live_n else leaf[dom]['launches']})
@@ -392,6 +391,7 @@ def main():
         # one entry per kernel family north_star asks evidence for (MFMA utilisation of the CBHG / post-net GEMMs,
         # achieved GB/s of the decoder loop, the BiGRU scan and the vocoder): one batch alone, HIP events per launch
         res['rooflines'] = [dict(roof(k, fam[k]['ms'] * 1e-3 / fam[k]['launches'], fam[k]['launches']),
+                                 traffic=tj.get(k, {}).get('bytes_per_launch'),
                                  measured='one batch alone, HIP event pair per launch')
                             for k in ('conv_gemm', 'bigru_scan', 'dec_persistent', 'decode_graph', 'gl_iter')
                             if k in fam and k in work]
