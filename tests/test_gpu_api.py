@@ -161,7 +161,8 @@ def test_cfg4_long_form(engine, hp, weights):
 
 
 def test_cfg5_icelandic_text(hp, weights):
-    """configs[4]: Icelandic charset through the same 95-symbol table (ids 75-84 present), B=1."""
+    """configs[4]: Icelandic charset through the same 95-symbol table (ids 75-84 present), B=1, in the hipGraph-captured
+    step chain the config names (decode mode 1) and in the default persistent kernel."""
     from tacotron_amd.model.tacotron import Tacotron
     from tacotron_amd.hparams import HParams
     from tacotron_amd.text.text_tools import text_to_onehot
@@ -169,9 +170,13 @@ def test_cfg5_icelandic_text(hp, weights):
     assert ((ids >= 75) & (ids <= 84)).any()
     lens = np.array([ids.shape[1]], np.int32)
     hp2 = HParams(max_iters=20)
-    m = Tacotron(hp2, weights=weights).initialize(ids, lens)
+    m = Tacotron(hp2, weights=weights)
     ref = O.tacotron_forward(ids, lens, weights, hp2)
-    assert rel_l1(_np(m.mel_outputs), ref['mel']) < 1e-3 and rel_l1(_np(m.linear_outputs), ref['linear']) < 1e-3
+    for mode in (1, 2):
+        m.engine.set_decode_graph(mode)
+        m.initialize(ids, lens)
+        assert rel_l1(_np(m.mel_outputs), ref['mel']) < 1e-3 and rel_l1(_np(m.linear_outputs), ref['linear']) < 1e-3
+        assert rel_l1(_np(m.alignments), ref['alignments']) < 1e-3
     m.engine.close()
 
 
