@@ -32,7 +32,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
-template <int BM, int BN>
+// POOL: the A operand is max(x[t], x[t+1]) (the max-pool folded into proj_1's loader); a template parameter so that the
+// k loop is one basic block, whose address arithmetic and loads the scheduler can spread between the MFMAs
+template <int BM, int BN, bool POOL>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     constexpr int BK = 16, PAD = 4, AST = BK + 4;   // A row stride 20: the 16 lanes of a ds_read_b128 group hit 16 bank quads
     constexpr int WM = BM / 2, WN = BN / 2;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
             const unsigned off = rowoff[i] + (unsigned)t2 * ldx4 + (unsigned)c0 * 4u;                    \
             const unsigned vo = ok ? off : OOB;                                                          \
             ra[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xr, vo, 0, 0));     \
-            if (a.pool) {                                                                                \
+            if (POOL) {                                                                                  \
                 const unsigned vo2 = (ok && t2 + 1 < a.T) ? off + ldx4 : vo;                             \
                 rp[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xr, vo2, 0, 0)); \
             }                                                                                            \
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
             const int f = tid + 256 * i;                                                                 \
             const int row = f >> 2, k = 4 * (f & 3);                                                     \
             f32x4v v = ra[i];                                                                            \
-            if (a.pool) v = __builtin_elementwise_max(v, rp[i]);                                         \
+            if (POOL) v = __builtin_elementwise_max(v, rp[i]);                                           \
             *reinterpret_cast<f32x4v*>(&As[buf][row][k]) = v;                                            \
         }                                                                                                \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                 \
@@ -190,7 +192,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
         int buf = 0;
         for (int kt = kt0; kt < kt1 - 1; ++kt) {
             CG_FETCH();              // tile kt+1 in flight under the MFMAs of tile kt
+            __builtin_amdgcn_sched_barrier(0);   // (the loads stay up here: sunk among the MFMAs they are waited for at once)
             CG_COMPUTE(buf);
+            __builtin_amdgcn_sched_barrier(0);   // (and what waits for them stays behind the MFMAs)
             CG_STASH(buf ^ 1);
             __syncthreads();
             buf ^= 1;
@@ -319,17 +323,21 @@ void launch_conv_gemm(const GemmArgs& a_in, hipStream_t s, Timing* tm) {
     static const char* tile_env = getenv("TACO_GEMM_TILE");     // (experiments: 64x128 or 128x64 for the big-tile cases)
     const bool big = (blocks128 >= 192 && a.N >= 128 && a.splitk == 1) || a.act == ACT_HIGHWAY_FUSED;
     if (big && tile_env && !strcmp(tile_env, "64x128")) {
-        hipLaunchKernelGGL((conv_gemm_kernel<64, 128>), cg_grid(a, 64, 128, z), dim3(256), 0, s, a);
+        if (a.pool) hipLaunchKernelGGL((conv_gemm_kernel<64, 128, true>), cg_grid(a, 64, 128, z), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<64, 128, false>), cg_grid(a, 64, 128, z), dim3(256), 0, s, a);
     } else if (big && a.act != ACT_HIGHWAY_FUSED && (tile_env ? !strcmp(tile_env, "128x64")
                                                               : (a.N <= 128 || (a.N % 128 != 0 && a.N % 128 <= 64)))) {
         // half-width tiles where a 128-wide one would be the only one of its row block (N = 128: twice the workgroups
         // per CU, measured 60 against 71 us at M = 32000, K = 640) or mostly padding (N = 1025: 180 against 196 us);
         // the k order of an element's sum is the same for every tile shape, so the choice does not change a bit
-        hipLaunchKernelGGL((conv_gemm_kernel<128, 64>), cg_grid(a, 128, 64, z), dim3(256), 0, s, a);
+        if (a.pool) hipLaunchKernelGGL((conv_gemm_kernel<128, 64, true>), cg_grid(a, 128, 64, z), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<128, 64, false>), cg_grid(a, 128, 64, z), dim3(256), 0, s, a);
     } else if (big) {
-        hipLaunchKernelGGL((conv_gemm_kernel<128, 128>), cg_grid(a, 128, 128, z), dim3(256), 0, s, a);
+        if (a.pool) hipLaunchKernelGGL((conv_gemm_kernel<128, 128, true>), cg_grid(a, 128, 128, z), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<128, 128, false>), cg_grid(a, 128, 128, z), dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL((conv_gemm_kernel<64, 64>), cg_grid(a, 64, 64, z), dim3(256), 0, s, a);
+        if (a.pool) hipLaunchKernelGGL((conv_gemm_kernel<64, 64, true>), cg_grid(a, 64, 64, z), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<64, 64, false>), cg_grid(a, 64, 64, z), dim3(256), 0, s, a);
         if (a.splitk > 1) {
             const int ldp = (a.N + 63) / 64 * 64;
             long n4 = (long)a.M * (ldp / 4);
