@@ -258,6 +258,9 @@ def main():
         """n_steps passes over the batch, `streams` in flight, bracketed by barrier + synchronise; max over ranks."""
         counter[0] = 0
         barrier()
+        # decodes side by side: as many as fit the chip for mel + linear; one at a time when the vocoder's full-chip
+        # launches of the other batches in flight run beside them (include/taco.h, taco_set_persist_budget)
+        eng.set_persist_budget(32 * ((B + 15) // 16) if to_wav else 0)
         t0 = time.perf_counter()
         for _ in range(n_steps):
             step(to_wav)

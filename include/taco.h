@@ -200,6 +200,16 @@ int32_t taco_num_kernel_kinds(void);
  * kernel for the whole loop (default layer sizes, no dropout replay, B <= 128; otherwise mode 1 is used). */
 int taco_set_decode_graph(taco_handle h, int32_t mode);
 
+/* Scheduling knob of the persistent decoder (no reference counterpart; TF's executor has nothing of the kind): the
+ * number of CUs that persistent decodes of THIS process may hold on `device` at the same time (each workgroup of a
+ * persistent decode owns a CU: 32 per 16 utterances). A decode that would exceed it waits, on its stream, for older
+ * ones to finish. 0 = the device's CU count (default: as many decodes side by side as fit the chip, best when the
+ * other kernels are short, i.e. mel + linear only); callers that also run the 60-iteration Griffin-Lim of other
+ * batches beside the decodes get more out of the chip with one decode at a time (budget = 32 * ceil(B / 16)): the
+ * vocoder's full-chip launches then always find three quarters of the CUs (measured 3.04 -> 3.28 M frames/s to the
+ * waveform at B = 32, six batches in flight). A single decode larger than the budget is still admitted, alone. */
+int taco_set_persist_budget(int32_t device, int32_t workgroups);
+
 /* Synchronous check of the last persistent decode (reads a few device words; call after the stream has been
  * synchronised): <0 if one of its bounded inter-workgroup waits timed out, in which case its outputs are invalid.
  * Failure handling of the persistent mode (no reference counterpart; the reference's loop is a tf.while_loop inside

@@ -872,12 +872,20 @@ namespace {
 struct PersistSlot { hipEvent_t ev; int wgs; };
 std::mutex g_persist_mu;
 std::map<int, std::vector<PersistSlot>> g_persist_active;   // per device, launch order
+std::map<int, int> g_persist_budget;                         // per device; absent / 0 = the CU count
 
 int persist_admit(int device, int wgs, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_persist_mu);
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
     if (wgs > cus) return -1;
+    // taco_set_persist_budget: fewer CUs than the device has for co-resident persistent decodes, the rest stay free for
+    // the GEMM / scan / vocoder kernels of the other batches in flight (a single larger decode is admitted alone)
+    {
+        auto it = g_persist_budget.find(device);
+        const int cap = it != g_persist_budget.end() ? it->second : 0;
+        if (cap > 0) cus = std::max(wgs, std::min(cus, cap));
+    }
     auto& v = g_persist_active[device];
     for (size_t i = 0; i < v.size();) {
         if (hipEventQuery(v[i].ev) == hipSuccess) { (void)hipEventDestroy(v[i].ev); v.erase(v.begin() + i); }
@@ -1324,6 +1332,13 @@ extern "C" int taco_timing_end(taco_handle h, int32_t* launches, double* total_m
 
 extern "C" const char* taco_kernel_name(int32_t kind) { return kind >= 0 && kind < KK_COUNT ? kKernelNames[kind] : ""; }
 extern "C" int32_t taco_num_kernel_kinds(void) { return KK_COUNT; }
+
+extern "C" int taco_set_persist_budget(int32_t device, int32_t workgroups) {
+    if (device < 0 || workgroups < 0) return fail("taco_set_persist_budget: negative argument");
+    std::lock_guard<std::mutex> lk(g_persist_mu);
+    g_persist_budget[device] = workgroups;
+    return 0;
+}
 
 extern "C" int taco_set_decode_graph(taco_handle h, int32_t mode) {
     if (!h) return fail("taco_set_decode_graph: null handle");

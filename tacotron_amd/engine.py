@@ -118,6 +118,12 @@ class TacoEngine:
         """0/False = eager per-stage kernels, 1/True = hipGraph replay of them, 2 = persistent kernel (default)."""
         self._check(self.lib.taco_set_decode_graph(self.handle, int(mode)))
 
+    def set_persist_budget(self, workgroups):
+        """CUs that persistent decodes of this process may hold on this engine's device at a time (0 = all): see
+        include/taco.h. One decode at a time (32 * ceil(B / 16)) is the better setting when vocoder launches of
+        other batches run beside the decodes."""
+        self._check(self.lib.taco_set_persist_budget(int(self.device.index or 0), int(workgroups)))
+
     def decode_status(self):
         """After a synchronisation: raises if the last persistent decode hit a barrier timeout."""
         self._check(self.lib.taco_decode_status(self.handle))

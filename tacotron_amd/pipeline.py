@@ -39,8 +39,16 @@ class SynthesisPipeline:
         self._set_outs = [[{} for _ in es] for es in self.sets]
         self._outs = self._set_outs[0]
 
+    def _set_budget(self, to_wav, batch):
+        """Decodes side by side: as many as fit the chip for mel + linear jobs; one at a time when the vocoder's
+        full-chip launches of other batches run beside them (include/taco.h, taco_set_persist_budget)."""
+        for es in self.sets:
+            es[0].set_persist_budget(32 * ((batch + 15) // 16) if to_wav else 0)
+
     def close(self):
         for es in self.sets:
+            if es:
+                es[0].set_persist_budget(0)          # (the budget is per process and device: leave the default behind)
             for e in es:
                 e.close()
         self.sets, self.engines = [], []
@@ -63,6 +71,7 @@ class SynthesisPipeline:
         if batch_size < 1:
             raise ValueError('batch_size must be >= 1')
         shards, plan = plan_batches(lens, len(self.sets), batch_size)
+        self._set_budget(to_wav, batch_size)
         tasks = collections.deque(plan)
         results = [[None] * len(idx) for idx in shards]                 # per set, in shard order
         filled = [0] * len(self.sets)
@@ -126,7 +135,11 @@ class SynthesisPipeline:
             e.stream.synchronize()
             return o
 
+        budget_set = False
         for ids, lens in batches:
+            if not budget_set:
+                self._set_budget(to_wav, int(ids.shape[0]))
+                budget_set = True
             if len(inflight) == n:
                 yield collect()
             i = k % n

@@ -220,6 +220,35 @@ def test_pipeline_in_flight_matches_lone_engine(engine, hp, weights):
             assert np.array_equal(o[name].numpy(), _np(ref[name])), name
 
 
+def test_persist_budget_serialises_decodes_without_changing_results(engine, hp, weights):
+    """taco_set_persist_budget: with room for one 16-utterance decode at a time, decodes of two engines issued
+    back to back still both complete (the second waits on its stream for the first) and give the bits of the
+    default budget; a decode larger than the budget is admitted alone; negative arguments are refused."""
+    import torch
+    from tacotron_amd.engine import TacoEngine, TacoError
+    rng = np.random.default_rng(5)
+    ids, lens = synth_ids(rng, 16, 24)
+    ids2, lens2 = synth_ids(rng, 20, 24)
+    S = 6
+    ref = _np(engine.synthesize(ids, lens, max_iters=S)['mel']).copy()
+    ref2 = _np(engine.synthesize(ids2, lens2, max_iters=S)['mel']).copy()
+    other = TacoEngine(weights, hp)
+    try:
+        engine.set_persist_budget(32)
+        a = engine.synthesize(ids, lens, max_iters=S)
+        b = other.synthesize(ids, lens, max_iters=S)
+        c = other.synthesize(ids2, lens2, max_iters=S)          # 64 workgroups > budget: runs alone
+        torch.cuda.synchronize()
+        engine.decode_status(); other.decode_status()
+        assert np.array_equal(_np(a['mel']), ref) and np.array_equal(_np(b['mel']), ref)
+        assert np.array_equal(_np(c['mel']), ref2)
+        with pytest.raises(TacoError):
+            engine.set_persist_budget(-1)
+    finally:
+        engine.set_persist_budget(0)
+        other.close()
+
+
 def test_synthesizer_extensions(tmp_path):
     """synthesize_long (split + one batch + join), synthesize_many (pipeline, input order kept), plot=True."""
     from tacotron_amd import synthesizer as S
