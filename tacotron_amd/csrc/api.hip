@@ -117,6 +117,9 @@ struct taco_ctx {
     // previous launch aborted. persist_broken: it did; the handle uses the captured per-stage path from then on.
     unsigned* host_status = nullptr;
     hipEvent_t status_ev = nullptr;
+    // Griffin-Lim of a batch as up to 4 utterance groups on streams of their own (gl_impl): created lazily, on first use
+    hipStream_t gl_streams[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t gl_fork = nullptr, gl_join[3] = {nullptr, nullptr, nullptr};
     bool status_pending = false;
     bool persist_broken = false;
     unsigned long long* dbg_stamps = nullptr;  // PD_STAMPS builds: 64 s_memrealtime stamps of one step
@@ -753,6 +756,11 @@ extern "C" void taco_destroy(taco_handle h) {
     }
     for (hipEvent_t e : h->timing.ev) (void)hipEventDestroy(e);
     if (h->status_ev) (void)hipEventDestroy(h->status_ev);
+    for (int g = 0; g < 3; ++g) {
+        if (h->gl_streams[g]) (void)hipStreamDestroy(h->gl_streams[g]);
+        if (h->gl_join[g]) (void)hipEventDestroy(h->gl_join[g]);
+    }
+    if (h->gl_fork) (void)hipEventDestroy(h->gl_fork);
     if (h->host_status) (void)hipHostFree(h->host_status);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
@@ -1144,14 +1152,51 @@ static int gl_impl(taco_ctx* c, const float* linear, int B, int T, int iters, fl
     if (!ws.ok()) return fail("taco_griffin_lim: workspace too small");
     GLPlan p{hp.n_fft, hp.hop_length, hp.win_length, hp.num_freq, c->twiddle, c->window, c->gl_image};
     launch_gl_mag(linear, mag, M * hp.num_freq, hp.min_level_db, hp.ref_level_db, hp.power, s, tm);
-    launch_gl_iter(p, fa, mag, fa, B, T, 1, s, tm);     // y0 = istft(mag, zero phase) (audio.py:191)
-    float* cur = fa;
-    float* nxt = fb;
-    for (int i = 0; i < iters; ++i) {                   // audio.py:192-195
-        launch_gl_iter(p, cur, mag, nxt, B, T, 0, s, tm);
-        std::swap(cur, nxt);
+    auto chain = [&](int b0, int nb, hipStream_t st, Timing* t) {
+        const size_t r0 = (size_t)b0 * T;
+        float* a0 = fa + r0 * hp.win_length;
+        float* a1 = fb + r0 * hp.win_length;
+        const float* mg = mag + r0 * hp.num_freq;
+        launch_gl_iter(p, a0, mg, a0, nb, T, 1, st, t);     // y0 = istft(mag, zero phase) (audio.py:191)
+        float* cur = a0;
+        float* nxt = a1;
+        for (int i = 0; i < iters; ++i) {                   // audio.py:192-195
+            launch_gl_iter(p, cur, mg, nxt, nb, T, 0, st, t);
+            std::swap(cur, nxt);
+        }
+        launch_gl_ola(p, cur, wav + (size_t)b0 * ((size_t)(T - 1) * hp.hop_length + hp.win_length), nb, T, st, t);
+    };
+    // An iteration of the whole batch is one launch that has to drain before the next may start: with workgroups that
+    // live for ~25 us and only four rounds of them per launch, the chip idles for a good part of every launch's last
+    // round. Utterances do not depend on each other, so a large batch runs as G groups of utterances, each a chain of
+    // its own on a stream of its own: the tail of one group's launch is filled by the other groups' launches.
+    // (Not when the caller captures `s` or when launches are being timed on `s`.)
+    static const int split_env = getenv("TACO_GL_SPLIT") ? atoi(getenv("TACO_GL_SPLIT")) : 1;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = s != nullptr && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    int G = std::min(std::min(split_env, 4), B / 8);
+    if (capturing || tm || s == nullptr) G = 1;
+    if (G > 1) {
+        for (int g = 0; g < G - 1 && G > 1; ++g) {
+            if (!c->gl_streams[g] && (hipStreamCreateWithFlags(&c->gl_streams[g], hipStreamNonBlocking) != hipSuccess ||
+                                      hipEventCreateWithFlags(&c->gl_join[g], hipEventDisableTiming) != hipSuccess))
+                G = 1;
+        }
+        if (!c->gl_fork && hipEventCreateWithFlags(&c->gl_fork, hipEventDisableTiming) != hipSuccess) G = 1;
     }
-    launch_gl_ola(p, cur, wav, B, T, s, tm);
+    if (G <= 1) {
+        chain(0, B, s, tm);
+        return 0;
+    }
+    HIP_OK(hipEventRecord(c->gl_fork, s));
+    for (int g = 1; g < G; ++g) {
+        hipStream_t st = c->gl_streams[g - 1];
+        HIP_OK(hipStreamWaitEvent(st, c->gl_fork, 0));
+        chain((int)((long)B * g / G), (int)((long)B * (g + 1) / G - (long)B * g / G), st, nullptr);
+        HIP_OK(hipEventRecord(c->gl_join[g - 1], st));
+    }
+    chain(0, (int)((long)B / G), s, nullptr);
+    for (int g = 1; g < G; ++g) HIP_OK(hipStreamWaitEvent(s, c->gl_join[g - 1], 0));
     return 0;
 }
 
