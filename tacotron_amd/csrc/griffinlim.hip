@@ -20,20 +20,41 @@
 
 namespace taco {
 
+// 10^(a p) on the hardware exp2: the exponent a p log2(10) is formed as a high part and a compensation term (the
+// rounding errors of the two products, recovered with fma), so the result is within about one ulp of the exact value;
+// the reference's (10^a)^p rounds the inner power to fp32 first, which this does not reproduce (nor does the fp64
+// oracle). Two library powf per element made this kernel run at 1 TB/s (0.26 ms for a batch of 32); now 4 elements a
+// lane per step, one v_exp_f32 each.
+__device__ __forceinline__ float gl_mag_one(float lin, float min_db, float ref_db, float power) {
+    float s = fminf(fmaxf(lin, 0.f), 1.f);
+    s = s * -min_db + min_db;                           // _denormalize_tensorflow (audio.py:276-277)
+    const float a = (s + ref_db) * 0.05f;               // exponent of _db_to_amp_tensorflow (audio.py:226-227)
+    constexpr float L_hi = 3.321928024291992f, L_lo = 7.0595369e-08f;   // log2(10) = L_hi + L_lo
+    const float z = a * power;                          // tf.pow(S, power) (audio.py:64): 10^(a power)
+    const float z_lo = __builtin_fmaf(a, power, -z);
+    const float x = z * L_hi;
+    const float x_lo = __builtin_fmaf(z, L_hi, -x) + __builtin_fmaf(z, L_lo, z_lo * L_hi);
+    const float e = __builtin_amdgcn_exp2f(x);
+    return __builtin_fmaf(e, x_lo * 0.6931471805599453f, e);
+}
+
 __global__ void gl_mag_kernel(const float* __restrict__ lin, float* __restrict__ mag, size_t n, float min_db,
                               float ref_db, float power) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float s = fminf(fmaxf(lin[i], 0.f), 1.f);
-        s = s * -min_db + min_db;                       // _denormalize_tensorflow (audio.py:276-277)
-        s = powf(10.f, (s + ref_db) * 0.05f);           // _db_to_amp_tensorflow (audio.py:226-227)
-        mag[i] = powf(s, power);                        // tf.pow(S, power) (audio.py:64)
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (size_t i = i0; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(lin)[i];
+        reinterpret_cast<float4*>(mag)[i] =
+            make_float4(gl_mag_one(v.x, min_db, ref_db, power), gl_mag_one(v.y, min_db, ref_db, power),
+                        gl_mag_one(v.z, min_db, ref_db, power), gl_mag_one(v.w, min_db, ref_db, power));
     }
+    for (size_t i = 4 * n4 + i0; i < n; i += stride) mag[i] = gl_mag_one(lin[i], min_db, ref_db, power);
 }
 
 void launch_gl_mag(const float* lin, float* mag, size_t n, float min_db, float ref_db, float power, hipStream_t s,
                    Timing* tm) {
     if (tm) tm->begin(KK_GL_MAG, s);
-    int blocks = (int)std::min<size_t>(4096, (n + 255) / 256);
+    int blocks = (int)std::min<size_t>(4096, (n / 4 + 255) / 256);
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(gl_mag_kernel, dim3(blocks), dim3(256), 0, s, lin, mag, n, min_db, ref_db, power);
     if (tm) tm->end(KK_GL_MAG, s);
