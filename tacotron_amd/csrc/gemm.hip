@@ -370,25 +370,40 @@ __global__ __launch_bounds__(256, 2) void cbhg_tail_kernel(CbhgTailArgs a) {
     // "layers": n_hw highway layers, then Nr / 256 column chunks of the input projection
     const int nrc = (a.Nr + BN - 1) / BN;
     const int nl = a.n_hw + nrc;
-    auto layer_w = [&](int L, int& ldw) -> const float* {
-        if (L < a.n_hw) { ldw = BN; return a.Whw[L]; }
-        ldw = a.ldwr;
-        return a.Wr + (L - a.n_hw) * BN;
-    };
+    // Base address of every weight chunk (16 k-rows of a layer's 256-column block), built once in LDS: the chunk loop
+    // then has no branches (a single basic block lets the compiler count its waits: the chunk two ahead stays in flight
+    // while the chunk one ahead is written to LDS) and does not index the kernel-argument pointer arrays with a
+    // run-time layer number, which costs a select chain over all eight entries per fetch. The loads go through a
+    // buffer resource made from the table entry, so they are plain vector-memory loads whatever the compiler knows
+    // about the pointer's origin.
+    const int nchunks = nl * NKT;
+    unsigned long long* ctab_s = reinterpret_cast<unsigned long long*>(tail_smem + BM * XS + 2 * BK * (BN + PAD));   // [12 * NKT]
+    for (int c = tid; c < nchunks; c += 256) {
+        const int L = c / NKT, kt = c % NKT;
+        const float* W;
+        int ldw;
+        if (L < a.n_hw) { ldw = BN; W = a.Whw[L]; }
+        else { ldw = a.ldwr; W = a.Wr + (L - a.n_hw) * BN; }
+        ctab_s[c] = reinterpret_cast<unsigned long long>(W + (size_t)(kt * BK) * ldw);
+    }
+    __syncthreads();
     // weight chunks are fetched TWO chunks ahead (two register sets, even / odd chunks): with one workgroup's 16 MFMAs
     // per chunk (BM = 32) a single chunk of run-ahead does not cover an L2 round trip
-    const int nchunks = nl * NKT;
     f32x4v rbA[NB], rbB[NB];
+    const int hw_chunks = a.n_hw * NKT;
     auto fetch = [&](f32x4v (&rb)[NB], int c) {
-        if (c >= nchunks) return;
-        int ldw;
-        const float* W = layer_w(c / NKT, ldw);
-        const int kt = c % NKT;
+        const int cc = min(c, nchunks - 1);                 // (past the end: the last chunk again, never used)
+        const unsigned long long base = ctab_s[cc];
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+        const int ldw = cc < hw_chunks ? BN : a.ldwr;
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, ((BK - 1) * ldw + BN) * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int f = tid + 256 * i;
             const int k = f / (BN / 4), nq = f % (BN / 4);
-            rb[i] = *reinterpret_cast<const f32x4v*>(W + (size_t)(kt * BK + k) * ldw + 4 * nq);
+            rb[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)(k * ldw + 4 * nq) * 4u, 0, 0));
         }
     };
     auto stash = [&](const f32x4v (&rb)[NB], int buf) {
@@ -449,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void cbhg_tail_kernel(CbhgTailArgs a) {
             __syncthreads();
             fetch(rbB, c + 3);
             compute(kt + 1, 1);
-            if (c + 2 < nchunks) stash(rbA, 0);
+            stash(rbA, 0);
             __syncthreads();
             fetch(rbA, c + 4);
         }
@@ -505,7 +520,7 @@ void launch_cbhg_tail(const CbhgTailArgs& a, hipStream_t s, Timing* tm) {
     // rows per workgroup: 64 when that still gives a workgroup per CU and more, else 32 (any choice gives the same bits)
     const bool big = (a.M + 63) / 64 >= 256;
     const int bm = big ? 64 : 32;
-    const size_t lds = ((size_t)bm * 132 + 2 * 16 * 260) * sizeof(float);
+    const size_t lds = ((size_t)bm * 132 + 2 * 16 * 260) * sizeof(float) + 12 * 8 * sizeof(unsigned long long);
     const dim3 grid((a.M + bm - 1) / bm);
     if (big) hipLaunchKernelGGL((cbhg_tail_kernel<64>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((cbhg_tail_kernel<32>), grid, dim3(256), lds, s, a);
