@@ -45,23 +45,116 @@ TACO_HD cplx cadd_pi(cplx a, cplx d) {
 // a * b and a * conj(b) for a twiddle b that comes from memory: the half-swapped, half-negated second factor of the
 // FMA is operand selection as well (the compiler builds it with a move and a sign flip per product; for compile-time
 // constant twiddles cmul folds them into literals and stays the better form). Bit-identical to cmul / cmul(a, cconj(b)).
+// (one asm statement per product, two per butterfly pair below: the compiler pads every asm statement with an s_nop
+// against hazards it cannot see into, 170 of them per pair of frames when each instruction was a statement of its own)
 TACO_HD cplx cmul_v(cplx a, cplx b) {
-    cplx t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    cplx r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(r) : "v"(a), "v"(b));
     return r;
 }
 TACO_HD cplx cmul_vc(cplx a, cplx b) {
-    cplx t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    cplx r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        : "=&v"(r) : "v"(a), "v"(b));
     return r;
+}
+// 3 products a_i <- a_i * b_i in one asm statement
+TACO_HD void cmul_v3(cplx& a0, cplx& a1, cplx& a2, cplx b0, cplx b1, cplx b2) {
+    cplx r0, r1, r2;
+    asm("v_pk_mul_f32 %0, %3, %6 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %3, %6, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_mul_f32 %1, %4, %7 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %1, %4, %7, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_mul_f32 %2, %5, %8 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %2, %5, %8, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(a0), "v"(a1), "v"(a2), "v"(b0), "v"(b1), "v"(b2));
+    a0 = r0;
+    a1 = r1;
+    a2 = r2;
+}
+// 3 products a_i <- a_i * conj b_i in one asm statement
+TACO_HD void cmul_vc3(cplx& a0, cplx& a1, cplx& a2, cplx b0, cplx b1, cplx b2) {
+    cplx r0, r1, r2;
+    asm("v_pk_mul_f32 %0, %3, %6 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %3, %6, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_mul_f32 %1, %4, %7 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %1, %4, %7, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_mul_f32 %2, %5, %8 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %2, %5, %8, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(a0), "v"(a1), "v"(a2), "v"(b0), "v"(b1), "v"(b2));
+    a0 = r0;
+    a1 = r1;
+    a2 = r2;
+}
+// 4 products a_i <- a_i * b_i in one asm statement
+TACO_HD void cmul_v4(cplx& a0, cplx& a1, cplx& a2, cplx& a3, cplx b0, cplx b1, cplx b2, cplx b3) {
+    cplx r0, r1, r2, r3;
+    asm("v_pk_mul_f32 %0, %4, %8 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %4, %8, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_mul_f32 %1, %5, %9 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %1, %5, %9, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_mul_f32 %2, %6, %10 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %2, %6, %10, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_mul_f32 %3, %7, %11 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %3, %7, %11, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+    a0 = r0;
+    a1 = r1;
+    a2 = r2;
+    a3 = r3;
+}
+// 4 products a_i <- a_i * conj b_i in one asm statement
+TACO_HD void cmul_vc4(cplx& a0, cplx& a1, cplx& a2, cplx& a3, cplx b0, cplx b1, cplx b2, cplx b3) {
+    cplx r0, r1, r2, r3;
+    asm("v_pk_mul_f32 %0, %4, %8 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %4, %8, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_mul_f32 %1, %5, %9 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %1, %5, %9, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_mul_f32 %2, %6, %10 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %2, %6, %10, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_mul_f32 %3, %7, %11 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %3, %7, %11, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+    a0 = r0;
+    a1 = r1;
+    a2 = r2;
+    a3 = r3;
+}
+// four (a - i d, a + i d) pairs in one statement
+TACO_HD void cadd_mi_pi4(const cplx (&a)[4], const cplx (&d)[4], cplx (&rm)[4], cplx (&rp)[4]) {
+    asm("v_pk_add_f32 %0, %8, %12 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %4, %8, %12 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %1, %9, %13 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %5, %9, %13 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %2, %10, %14 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %6, %10, %14 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %3, %11, %15 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %7, %11, %15 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"
+        : "=&v"(rm[0]), "=&v"(rm[1]), "=&v"(rm[2]), "=&v"(rm[3]), "=&v"(rp[0]), "=&v"(rp[1]), "=&v"(rp[2]), "=&v"(rp[3])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]));
+}
+// (a - i d, a + i d) together
+TACO_HD void cadd_mi_pi(cplx a, cplx d, cplx& rm, cplx& rp) {
+    asm("v_pk_add_f32 %0, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"
+        : "=&v"(rm), "=&v"(rp) : "v"(a), "v"(d));
 }
 #else
 TACO_HD cplx cadd_mi(cplx a, cplx d) { return cplx{a.x + d.y, a.y - d.x}; }
 TACO_HD cplx cadd_pi(cplx a, cplx d) { return cplx{a.x - d.y, a.y + d.x}; }
 TACO_HD cplx cmul_v(cplx a, cplx b) { return cmul(a, b); }
 TACO_HD cplx cmul_vc(cplx a, cplx b) { return cmul(a, cconj(b)); }
+TACO_HD void cadd_mi_pi(cplx a, cplx d, cplx& rm, cplx& rp) { rm = cadd_mi(a, d); rp = cadd_pi(a, d); }
+TACO_HD void cadd_mi_pi4(const cplx (&a)[4], const cplx (&d)[4], cplx (&rm)[4], cplx (&rp)[4]) {
+    for (int i = 0; i < 4; ++i) { rm[i] = cadd_mi(a[i], d[i]); rp[i] = cadd_pi(a[i], d[i]); }
+}
+TACO_HD void cmul_v3(cplx& a0, cplx& a1, cplx& a2, cplx b0, cplx b1, cplx b2) { a0 = cmul_v(a0, b0); a1 = cmul_v(a1, b1); a2 = cmul_v(a2, b2); }
+TACO_HD void cmul_vc3(cplx& a0, cplx& a1, cplx& a2, cplx b0, cplx b1, cplx b2) { a0 = cmul_vc(a0, b0); a1 = cmul_vc(a1, b1); a2 = cmul_vc(a2, b2); }
+TACO_HD void cmul_v4(cplx& a0, cplx& a1, cplx& a2, cplx& a3, cplx b0, cplx b1, cplx b2, cplx b3) { a0 = cmul_v(a0, b0); a1 = cmul_v(a1, b1); a2 = cmul_v(a2, b2); a3 = cmul_v(a3, b3); }
+TACO_HD void cmul_vc4(cplx& a0, cplx& a1, cplx& a2, cplx& a3, cplx b0, cplx b1, cplx b2, cplx b3) { a0 = cmul_vc(a0, b0); a1 = cmul_vc(a1, b1); a2 = cmul_vc(a2, b2); a3 = cmul_vc(a3, b3); }
 #endif
 #else
 struct cplx {
@@ -75,6 +168,14 @@ TACO_HD cplx cadd_mi(cplx a, cplx d) { return {a.x + d.y, a.y - d.x}; }
 TACO_HD cplx cadd_pi(cplx a, cplx d) { return {a.x - d.y, a.y + d.x}; }
 TACO_HD cplx cmul_v(cplx a, cplx b) { return cmul(a, b); }
 TACO_HD cplx cmul_vc(cplx a, cplx b) { return cmul(a, cconj(b)); }
+TACO_HD void cadd_mi_pi(cplx a, cplx d, cplx& rm, cplx& rp) { rm = cadd_mi(a, d); rp = cadd_pi(a, d); }
+TACO_HD void cadd_mi_pi4(const cplx (&a)[4], const cplx (&d)[4], cplx (&rm)[4], cplx (&rp)[4]) {
+    for (int i = 0; i < 4; ++i) { rm[i] = cadd_mi(a[i], d[i]); rp[i] = cadd_pi(a[i], d[i]); }
+}
+TACO_HD void cmul_v3(cplx& a0, cplx& a1, cplx& a2, cplx b0, cplx b1, cplx b2) { a0 = cmul_v(a0, b0); a1 = cmul_v(a1, b1); a2 = cmul_v(a2, b2); }
+TACO_HD void cmul_vc3(cplx& a0, cplx& a1, cplx& a2, cplx b0, cplx b1, cplx b2) { a0 = cmul_vc(a0, b0); a1 = cmul_vc(a1, b1); a2 = cmul_vc(a2, b2); }
+TACO_HD void cmul_v4(cplx& a0, cplx& a1, cplx& a2, cplx& a3, cplx b0, cplx b1, cplx b2, cplx b3) { a0 = cmul_v(a0, b0); a1 = cmul_v(a1, b1); a2 = cmul_v(a2, b2); a3 = cmul_v(a3, b3); }
+TACO_HD void cmul_vc4(cplx& a0, cplx& a1, cplx& a2, cplx& a3, cplx b0, cplx b1, cplx b2, cplx b3) { a0 = cmul_vc(a0, b0); a1 = cmul_vc(a1, b1); a2 = cmul_vc(a2, b2); a3 = cmul_vc(a3, b3); }
 #endif
 
 constexpr int FFT_N = 1024;                 // complex length
@@ -91,9 +192,9 @@ TACO_HD void dft4(cplx& a0, cplx& a1, cplx& a2, cplx& a3) {
     const cplx v2 = cadd(a1, a3);
     const cplx d = csub(a1, a3);
     a0 = cadd(v0, v2);
-    a1 = INV ? cadd_pi(v1, d) : cadd_mi(v1, d);   // v1 + d * (+i) : v1 + d * (-i)
     a2 = csub(v0, v2);
-    a3 = INV ? cadd_mi(v1, d) : cadd_pi(v1, d);
+    if (INV) cadd_mi_pi(v1, d, a3, a1);           // a1 = v1 + d * (+i), a3 = v1 + d * (-i)
+    else cadd_mi_pi(v1, d, a1, a3);               // a1 = v1 + d * (-i), a3 = v1 + d * (+i)
 }
 
 // w16^n = exp(-2 pi i n / 16) for the products n = a2 * c1 that occur (0,1,2,3,4,6,9)
@@ -113,13 +214,37 @@ TACO_HD cplx w16(int n) {
     return INV ? cconj(w) : w;
 }
 
-// 16-point DFT in place, natural order in and out (index a = 4 a1 + a2, c = c1 + 4 c2).
-template <bool INV>
-TACO_HD void dft16(cplx (&v)[16]) {
+// Four independent 4-point DFTs in place: DFT j works on v[o + j sj + i si], i = 0..3; the four pairs of +-i rotations
+// are one statement (cadd_mi_pi4).
+template <bool INV, int O, int SJ, int SI, int N>
+TACO_HD void dft4x4(cplx (&v)[N]) {
+    cplx v1[4], d[4], rm[4], rp[4];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int a2 = 0; a2 < 4; ++a2) dft4<INV>(v[a2], v[4 + a2], v[8 + a2], v[12 + a2]);   // -> v[4 c1 + a2]
+    for (int j = 0; j < 4; ++j) {
+        cplx &a0 = v[O + j * SJ], &a1 = v[O + j * SJ + SI], &a2 = v[O + j * SJ + 2 * SI], &a3 = v[O + j * SJ + 3 * SI];
+        const cplx v0 = cadd(a0, a2);
+        v1[j] = csub(a0, a2);
+        const cplx v2 = cadd(a1, a3);
+        d[j] = csub(a1, a3);
+        a0 = cadd(v0, v2);
+        a2 = csub(v0, v2);
+    }
+    cadd_mi_pi4(v1, d, rm, rp);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 4; ++j) {
+        v[O + j * SJ + SI] = INV ? rp[j] : rm[j];          // v1 + d * (+i) : v1 + d * (-i)
+        v[O + j * SJ + 3 * SI] = INV ? rm[j] : rp[j];
+    }
+}
+
+// 16-point DFT in place, natural order in and out (index a = 4 a1 + a2, c = c1 + 4 c2).
+template <bool INV>
+TACO_HD void dft16(cplx (&v)[16]) {
+    dft4x4<INV, 0, 1, 4>(v);                 // DFT a2 over (v[a2], v[4 + a2], v[8 + a2], v[12 + a2]) -> v[4 c1 + a2]
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -128,10 +253,7 @@ TACO_HD void dft16(cplx (&v)[16]) {
 #pragma unroll
 #endif
         for (int a2 = 1; a2 < 4; ++a2) v[4 * c1 + a2] = cmul(v[4 * c1 + a2], w16<INV>(a2 * c1));
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (int c1 = 0; c1 < 4; ++c1) dft4<INV>(v[4 * c1], v[4 * c1 + 1], v[4 * c1 + 2], v[4 * c1 + 3]);   // -> v[4 c1 + c2]
+    dft4x4<INV, 0, 4, 1>(v);                 // DFT c1 over v[4 c1 .. 4 c1 + 3] -> v[4 c1 + c2]
     cplx o[16];
 #if defined(__HIPCC__)
 #pragma unroll

@@ -344,31 +344,33 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __r
 
 // first-stage DFT-16 of a vector whose elements 10..15 are zero (natural order in and out, as dft16<false>)
 __device__ __forceinline__ void dft16_fwd_in10(cplx (&v)[16]) {
+    cplx v1[4], d[4], rm[4], rp[4];
 #pragma unroll
     for (int a2 = 0; a2 < 2; ++a2) {          // (v[a2], v[4+a2], v[8+a2], 0)
         const cplx v0 = cadd(v[a2], v[8 + a2]);
-        const cplx v1 = csub(v[a2], v[8 + a2]);
-        const cplx v2 = v[4 + a2];
-        v[a2] = cadd(v0, v2);
-        v[4 + a2] = cadd_mi(v1, v2);          // v1 + v2 * (-i)
-        v[8 + a2] = csub(v0, v2);
-        v[12 + a2] = cadd_pi(v1, v2);
+        v1[a2] = csub(v[a2], v[8 + a2]);
+        d[a2] = v[4 + a2];
+        v[a2] = cadd(v0, d[a2]);
+        v[8 + a2] = csub(v0, d[a2]);
     }
 #pragma unroll
     for (int a2 = 2; a2 < 4; ++a2) {          // (v[a2], v[4+a2], 0, 0)
-        const cplx v0 = v[a2];
-        const cplx v2 = v[4 + a2];
-        v[a2] = cadd(v0, v2);
-        v[4 + a2] = cadd_mi(v0, v2);
-        v[8 + a2] = csub(v0, v2);
-        v[12 + a2] = cadd_pi(v0, v2);
+        v1[a2] = v[a2];
+        d[a2] = v[4 + a2];
+        v[a2] = cadd(v1[a2], d[a2]);
+        v[8 + a2] = csub(v1[a2], d[a2]);
+    }
+    cadd_mi_pi4(v1, d, rm, rp);               // v1 + d * (-i), v1 + d * (+i)
+#pragma unroll
+    for (int a2 = 0; a2 < 4; ++a2) {
+        v[4 + a2] = rm[a2];
+        v[12 + a2] = rp[a2];
     }
 #pragma unroll
     for (int c1 = 1; c1 < 4; ++c1)
 #pragma unroll
         for (int a2 = 1; a2 < 4; ++a2) v[4 * c1 + a2] = cmul(v[4 * c1 + a2], w16<false>(a2 * c1));
-#pragma unroll
-    for (int c1 = 0; c1 < 4; ++c1) dft4<false>(v[4 * c1], v[4 * c1 + 1], v[4 * c1 + 2], v[4 * c1 + 3]);
+    dft4x4<false, 0, 4, 1>(v);
     cplx o[16];
 #pragma unroll
     for (int c1 = 0; c1 < 4; ++c1)
@@ -445,11 +447,26 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
     // cache between iterations) are long back when the first re-phasing needs them; the next pair's are requested when
     // this pair's are dead (after m4)
     float mkA[8], mnA[8], m512A, mkB[8], mnB[8], m512B;
+    // The lane's eight bin pairs (k, 1024 - k), in the order the last forward pass leaves them in its registers (see
+    // x_pass2 below): k = l, 256 + l, t3, 256 + t3, 64 + l, 320 + l, 192 - l, 448 - l with t3 = 256 - l (128 in lane 0)
+    const int t3l = lane ? 256 - lane : 128;
+    auto pair_bin = [&](int j) {
+        switch (j) {
+            case 0: return lane;
+            case 1: return 256 + lane;
+            case 2: return t3l;
+            case 3: return 256 + t3l;
+            case 4: return 64 + lane;
+            case 5: return 320 + lane;
+            case 6: return 192 - lane;
+            default: return 448 - lane;
+        }
+    };
     auto load_mag = [&](float (&mk)[8], float (&mn)[8], float& m512, int fi) {
         const float* mg = mag + (fb + m0 + fi) * nbins;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = lane + 64 * j;
+            const int k = pair_bin(j);
             mk[j] = mg[k];
             mn[j] = mg[FFT_N - k];
         }
@@ -567,10 +584,6 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
 #pragma unroll
             for (int i = 0; i < 3; ++i) tw[3 * q + i] = T3[i * 256 + lane + 64 * q];
     };
-    auto ld_wk = [&]() {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) tw[j] = wk_s[lane + 64 * j];
-    };
     auto a1 = [&](Fr& f) {
         // analysis window, even/odd packing z[c] = (y[2c], y[2c+1]), c = lane + 64 i: i <= 8 always inside the window,
         // i = 9 for the first HALF - 576 lanes, i >= 10 never
@@ -591,80 +604,130 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
         for (int c = 0; c < 16; ++c) lds[fft_pad(16 * lane + c)] = f.v[c];
         fft_load(f.v, lds, lane);
     };
+    // Pass 2 writes y2[(t - k) 16 + k + 16 c]; the radix-4 pass that follows reads butterfly t's inputs y2[t + 256 i].
+    // Which four butterflies a lane takes is free: here t = l, 64 + l, 192 - l, 256 - l (lane 0: 0, 64, 192, 128), so
+    // that the outputs X[t + 256 i'] of a lane contain BOTH members of each of its eight bin pairs (k, 1024 - k): the
+    // split / re-phase / merge of the real transform then works on registers alone, with no partner exchange through
+    // LDS before and after it, and the inverse transform runs the three passes backwards from the same registers.
     auto x_pass2 = [&](Fr& f) {
         const int base = (lane >> 4) * 256 + (lane & 15);
 #pragma unroll
         for (int c = 0; c < 16; ++c) lds[fft_pad(base + 16 * c)] = f.v[c];
-        fft_load(f.v, lds, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f.v[4 * i] = lds[fft_pad(lane + 256 * i)];
+            f.v[4 * i + 1] = lds[fft_pad(64 + lane + 256 * i)];
+            f.v[4 * i + 2] = lds[fft_pad(192 - lane + 256 * i)];
+            f.v[4 * i + 3] = lds[fft_pad(t3l + 256 * i)];
+        }
     };
     auto m2f = [&](Fr& f) {
-#pragma unroll
-        for (int i = 1; i < 16; ++i) f.v[i] = cmul_v(f.v[i], tw[i - 1]);
+        cplx (&v)[16] = f.v;
+        cmul_v4(v[1], v[2], v[3], v[4], tw[0], tw[1], tw[2], tw[3]);
+        cmul_v4(v[5], v[6], v[7], v[8], tw[4], tw[5], tw[6], tw[7]);
+        cmul_v4(v[9], v[10], v[11], v[12], tw[8], tw[9], tw[10], tw[11]);
+        cmul_v3(v[13], v[14], v[15], tw[12], tw[13], tw[14]);
     };
-    auto m2i = [&](Fr& f) {
-#pragma unroll
-        for (int i = 1; i < 16; ++i) f.v[i] = cmul_vc(f.v[i], tw[i - 1]);
-    };
-    auto m3 = [&](Fr& f) {                               // -> v[m] = Z[lane + 64 m]
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int i = 1; i < 4; ++i) f.v[q + 4 * i] = cmul_v(f.v[q + 4 * i], tw[3 * q + i - 1]);
-            dft4<false>(f.v[q], f.v[q + 4], f.v[q + 8], f.v[q + 12]);
+    // Radix-4 pass (tw = T3 of the lane's butterflies) -> v[s + 4 i'] = Z[t_s + 256 i']; bin pairs in registers
+    // (0,15) (4,11) (3,12) (7,8) (1,14) (5,10) (2,13) (6,9) = pair_bin order; split -> re-phase against the target
+    // magnitude -> merge as before (unnormalised, the halvings go into the final scale); then the radix-4 pass backwards.
+    // Lane 0 holds the self-paired bins: Z[0] (pairs with itself: DC and Nyquist), Z[512] (conjugate of itself) and the
+    // pairs (256, 768), (128, 896), (384, 640), which sit in other registers than the generic pattern expects: four of
+    // its registers are rotated into the generic places before and back after.
+    auto m3 = [&](Fr& f, const float (&mk)[8], const float (&mn)[8], float m512) {
+        // (tw[3 q + i - 1]: twiddle of input i of butterfly q; three statements of four products)
+        cmul_v4(f.v[4], f.v[8], f.v[12], f.v[5], tw[0], tw[1], tw[2], tw[3]);
+        cmul_v4(f.v[9], f.v[13], f.v[6], f.v[10], tw[4], tw[5], tw[6], tw[7]);
+        cmul_v4(f.v[14], f.v[7], f.v[11], f.v[15], tw[8], tw[9], tw[10], tw[11]);
+        dft4x4<false, 0, 1, 4>(f.v);
+        const bool l0 = lane == 0;
+        cplx z512 = f.v[8];
+        {
+            const cplx a8 = f.v[8], a11 = f.v[11], a12 = f.v[12], a15 = f.v[15];
+            f.v[8] = l0 ? a11 : a8;
+            f.v[11] = l0 ? a12 : a11;
+            f.v[12] = l0 ? a15 : a12;
+            f.v[15] = l0 ? f.v[0] : a15;
         }
-        f.z512 = f.v[8];                                 // lane 0: Z[512]
+        constexpr int RK[8] = {0, 4, 3, 7, 1, 5, 2, 6}, RN[8] = {15, 11, 12, 8, 14, 10, 13, 9};
+#pragma unroll
+        for (int h = 0; h < 8; h += 4) {                 // four pairs at a time: their rotations and twiddle products
+            cplx Wk[4], E[4], Tt[4], Xk[4], Un[4];       // are one statement each
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Wk[j] = wk_s[lane + 64 * (h + j)];
+                const cplx zk = f.v[RK[h + j]];
+                const cplx cn = cconj(f.v[RN[h + j]]);
+                E[j] = cadd(zk, cn);
+                Tt[j] = csub(zk, cn);
+            }
+            cmul_v4(Tt[0], Tt[1], Tt[2], Tt[3], Wk[0], Wk[1], Wk[2], Wk[3]);
+            cadd_mi_pi4(E, Tt, Xk, Un);                   // 2 X[k], conj(2 X[1024 - k])
+            cplx E2[4], O2[4], zm[4], zp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float ak = __builtin_fmaf(Xk[j].x, Xk[j].x, Xk[j].y * Xk[j].y);
+                const float an = __builtin_fmaf(Un[j].x, Un[j].x, Un[j].y * Un[j].y);
+                const cplx Yk = Xk[j] * (mk[h + j] * __builtin_amdgcn_rsqf(ak > 4e-16f ? ak : 4e-16f));   // Y[k]
+                const cplx Vn = Un[j] * (mn[h + j] * __builtin_amdgcn_rsqf(an > 4e-16f ? an : 4e-16f));   // conj(Y[1024 - k])
+                E2[j] = cadd(Yk, Vn);
+                O2[j] = csub(Yk, Vn);
+            }
+            cmul_vc4(O2[0], O2[1], O2[2], O2[3], Wk[0], Wk[1], Wk[2], Wk[3]);
+            cadd_mi_pi4(E2, O2, zm, zp);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f.v[RK[h + j]] = zp[j];                   // 2 Z'[k]
+                f.v[RN[h + j]] = cconj(zm[j]);            // 2 Z'[1024 - k]
+            }
+        }
+        // bin 512 pairs with itself: X512 = conj(Z512), Z'512 = conj(Y512)
+        z512 = cconj(gl_rephase(cconj(z512), 2.f * m512));
+        {
+            const cplx a8 = f.v[8], a11 = f.v[11], a12 = f.v[12], a15 = f.v[15];
+            f.v[11] = l0 ? a8 : a11;
+            f.v[12] = l0 ? a11 : a12;
+            f.v[15] = l0 ? a12 : a15;
+            f.v[8] = l0 ? z512 : a8;
+        }
+        dft4x4<true, 0, 1, 4>(f.v);
+        cmul_vc4(f.v[4], f.v[8], f.v[12], f.v[5], tw[0], tw[1], tw[2], tw[3]);
+        cmul_vc4(f.v[9], f.v[13], f.v[6], f.v[10], tw[4], tw[5], tw[6], tw[7]);
+        cmul_vc4(f.v[14], f.v[7], f.v[11], f.v[15], tw[8], tw[9], tw[10], tw[11]);
     };
+    // the exchanges of the inverse are the forward ones backwards: written where the forward pass read, read where it wrote
     auto x3 = [&](Fr& f) {
-        // upper half to LDS in natural order, then the partner bins 1024 - k of the pairs (k, 1024 - k),
-        // k = lane + 64 j, into v[8 + j]. Pair 0 of lane 0 is (0, 1024): its slot fft_pad(1024) is a dummy behind
-        // the buffer, Z[1024] = Z[0] is substituted in m4.
 #pragma unroll
-        for (int i = 8; i < 16; ++i) lds[fft_pad(lane + 64 * i)] = f.v[i];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f.v[8 + j] = lds[fft_pad(FFT_N - (lane + 64 * j))];
-    };
-    auto m4 = [&](Fr& f, const float (&mk)[8], const float (&mn)[8], float m512) {
-        // split -> re-phase against the target magnitude -> merge on the bin pairs; v[j] = Z'[k], v[8 + j] = Z'[1024 - k].
-        // The halvings of the split and of the merge (rfft_split, irfft_merge) are left out: the re-phasing divides by
-        // |X| anyway (2X against 2 max(1e-8, |X|) is the same quotient), and the merge's factor 1/2 goes into the
-        // 1/1024 of the inverse transform (m7). With T = W (Zk - conj Zn): 2 X[k] = E - i T, conj(2 X[1024-k]) = E + i T.
-        f.v[8] = lane == 0 ? f.v[0] : f.v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const cplx Wk = tw[j];
-            const cplx cn = cconj(f.v[8 + j]);
-            const cplx E = cadd(f.v[j], cn);
-            const cplx Tt = cmul_v(csub(f.v[j], cn), Wk);
-            const cplx Xk = cadd_mi(E, Tt);               // 2 X[k]
-            const cplx Un = cadd_pi(E, Tt);               // conj(2 X[1024 - k])
-            const float ak = __builtin_fmaf(Xk.x, Xk.x, Xk.y * Xk.y), an = __builtin_fmaf(Un.x, Un.x, Un.y * Un.y);
-            const cplx Yk = Xk * (mk[j] * __builtin_amdgcn_rsqf(ak > 4e-16f ? ak : 4e-16f));      // Y[k]
-            const cplx Vn = Un * (mn[j] * __builtin_amdgcn_rsqf(an > 4e-16f ? an : 4e-16f));      // conj(Y[1024 - k])
-            const cplx E2 = cadd(Yk, Vn);
-            const cplx O2 = cmul_vc(csub(Yk, Vn), Wk);
-            f.v[j] = cadd_pi(E2, O2);                     // 2 Z'[k]
-            f.v[8 + j] = cconj(cadd_mi(E2, O2));          // 2 Z'[1024 - k]
+        for (int i = 0; i < 4; ++i) {
+            lds[fft_pad(lane + 256 * i)] = f.v[4 * i];
+            lds[fft_pad(64 + lane + 256 * i)] = f.v[4 * i + 1];
+            lds[fft_pad(192 - lane + 256 * i)] = f.v[4 * i + 2];
+            lds[fft_pad(t3l + 256 * i)] = f.v[4 * i + 3];
         }
-        // bin 512 pairs with itself: X512 = conj(Z512), Z'512 = conj(Y512); it is element 8 of lane 0
-        f.z512 = cconj(gl_rephase(cconj(f.z512), 2.f * m512));
+        const int base = (lane >> 4) * 256 + (lane & 15);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) f.v[c] = lds[fft_pad(base + 16 * c)];
+    };
+    // pass 2 backwards: inverse 16-point DFT, then the conjugate twiddles (read at their use: by then the other frame's
+    // exchange, issued a whole butterfly earlier, has landed)
+    auto m2i = [&](Fr& f) {
+        dft16<true>(f.v);
+        cplx (&v)[16] = f.v;
+        const cplx* t2 = T2 + (lane & 15);
+        cmul_vc4(v[1], v[2], v[3], v[4], t2[0], t2[16], t2[32], t2[48]);
+        cmul_vc4(v[5], v[6], v[7], v[8], t2[64], t2[80], t2[96], t2[112]);
+        cmul_vc4(v[9], v[10], v[11], v[12], t2[128], t2[144], t2[160], t2[176]);
+        cmul_vc3(v[13], v[14], v[15], t2[192], t2[208], t2[224]);
     };
     auto x4 = [&](Fr& f) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) lds[fft_pad(FFT_N - (lane + 64 * j))] = f.v[8 + j];   // (lane 0, j = 0: dummy slot)
+        for (int i = 0; i < 16; ++i) lds[fft_pad(lane + 64 * i)] = f.v[i];
 #pragma unroll
-        for (int i = 8; i < 16; ++i) f.v[i] = lds[fft_pad(lane + 64 * i)];
+        for (int c = 0; c < 16; ++c) f.v[c] = lds[fft_pad(16 * lane + c)];
     };
-    auto m5 = [&](Fr& f) {
-        f.v[8] = lane == 0 ? f.z512 : f.v[8];
-        dft16<true>(f.v);
-    };
+    // pass 1 backwards: v[i] = 1024 z'[lane + 64 i]; window, store
     auto m7 = [&](Fr& f, bool store) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int i = 1; i < 4; ++i) f.v[q + 4 * i] = cmul_vc(f.v[q + 4 * i], tw[3 * q + i - 1]);
-            dft4<true>(f.v[q], f.v[q + 4], f.v[q + 8], f.v[q + 12]);
-        }
+        dft16<true>(f.v);
         const float sc = 0.5f / FFT_N;                   // (1/1024 of the inverse transform, 1/2 of the merge)
         if (store) {
 #pragma unroll
@@ -695,20 +758,16 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
         m2f(A);  dft16<false>(A.v);  GL2_LAND(Bf.v); x_pass2(A);
         m2f(Bf); ld_T3(); dft16<false>(Bf.v); GL2_LAND(A.v);  x_pass2(Bf);
         GL_STAMP(sb + 2);
-        m3(A);   GL2_LAND(Bf.v); x3(A);
-        m3(Bf);  ld_wk(); GL2_LAND(A.v);  x3(Bf);
-        GL_STAMP(sb + 3);
         const int fn = fi + 2 * GL_WAVES;               // the wave's next pair
-        m4(A, mkA, mnA, m512A);   GL2_LAND(Bf.v); x4(A);
+        m3(A, mkA, mnA, m512A);   GL2_LAND(Bf.v); x3(A);
         if (fn < nfr) load_mag(mkA, mnA, m512A, fn);
-        m4(Bf, mkB, mnB, m512B);  GL2_LAND(A.v);  x4(Bf);
+        GL_STAMP(sb + 3);
+        m3(Bf, mkB, mnB, m512B);  GL2_LAND(A.v);  x3(Bf);
         if (fn < nfr) load_mag(mkB, mnB, m512B, min(fn + GL_WAVES, nfr - 1));
         GL_STAMP(sb + 4);
-        m5(A);   GL2_LAND(Bf.v); x_pass1(A);  ld_T2();
-        m5(Bf);  GL2_LAND(A.v);  x_pass1(Bf);
+        m2i(A);  GL2_LAND(Bf.v); x4(A);
         GL_STAMP(sb + 5);
-        m2i(A);  dft16<true>(A.v);  GL2_LAND(Bf.v); x_pass2(A);
-        m2i(Bf); ld_T3(); dft16<true>(Bf.v); GL2_LAND(A.v);  x_pass2(Bf);
+        m2i(Bf); GL2_LAND(A.v);  x4(Bf);
         GL_STAMP(sb + 6);
         m7(A, true);
         GL2_LAND(Bf.v);
@@ -739,18 +798,30 @@ extern "C" int taco_debug_gl_stamps(unsigned long long* out64) {
 }
 #endif
 
-// [window | T2, T3 (fft_tw_entry) | W[0..511]] as floats, the order gl_iter2_kernel carves its LDS in
+// [window | T2 (fft_tw_entry), T3 and split twiddles in gl_iter2_kernel's lane order] as floats, the order it carves its LDS in
 std::vector<float> gl_lds_image(const std::vector<float>& tw, const std::vector<float>& win) {
     std::vector<float> img(win);
     auto W = [&](int j) { return std::pair<float, float>(tw[2 * j], tw[2 * j + 1]); };
     for (int e = 0; e < FFT_TW; ++e) {
         int j;
         if (e < FFT_T2) j = 8 * (e % 16) * (e / 16 + 1);
-        else { const int e2 = e - FFT_T2; j = 2 * (e2 % 256) * (e2 / 256 + 1); }
+        else {
+            // radix-4 pass: entry 64 s + l of a row belongs to butterfly t_s(l) of lane l (gl_iter2_kernel, x_pass2)
+            const int e2 = e - FFT_T2, s = (e2 % 256) / 64, l = e2 % 64;
+            const int t = s == 0 ? l : (s == 1 ? 64 + l : (s == 2 ? 192 - l : (l ? 256 - l : 128)));
+            j = 2 * t * (e2 / 256 + 1);
+        }
         img.push_back(W(j).first);
         img.push_back(W(j).second);
     }
-    for (int j = 0; j < FFT_N / 2; ++j) { img.push_back(W(j).first); img.push_back(W(j).second); }
+    // split / merge twiddles W[k] of the lane's bin pairs, entry l + 64 j = pair j of lane l (pair_bin in the kernel)
+    for (int e = 0; e < FFT_N / 2; ++e) {
+        const int l = e % 64, t3 = l ? 256 - l : 128;
+        const int ks[8] = {l, 256 + l, t3, 256 + t3, 64 + l, 320 + l, 192 - l, 448 - l};
+        const int k = ks[e / 64];
+        img.push_back(W(k).first);
+        img.push_back(W(k).second);
+    }
     while (img.size() % 4) img.push_back(0.f);
     return img;
 }
