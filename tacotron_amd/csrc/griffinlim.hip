@@ -708,16 +708,14 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
 #pragma unroll
         for (int c = 0; c < 16; ++c) f.v[c] = lds[fft_pad(base + 16 * c)];
     };
-    // pass 2 backwards: inverse 16-point DFT, then the conjugate twiddles (read at their use: by then the other frame's
-    // exchange, issued a whole butterfly earlier, has landed)
+    // pass 2 backwards: inverse 16-point DFT, then the conjugate twiddles (tw = T2 again, read once per pair)
     auto m2i = [&](Fr& f) {
         dft16<true>(f.v);
         cplx (&v)[16] = f.v;
-        const cplx* t2 = T2 + (lane & 15);
-        cmul_vc4(v[1], v[2], v[3], v[4], t2[0], t2[16], t2[32], t2[48]);
-        cmul_vc4(v[5], v[6], v[7], v[8], t2[64], t2[80], t2[96], t2[112]);
-        cmul_vc4(v[9], v[10], v[11], v[12], t2[128], t2[144], t2[160], t2[176]);
-        cmul_vc3(v[13], v[14], v[15], t2[192], t2[208], t2[224]);
+        cmul_vc4(v[1], v[2], v[3], v[4], tw[0], tw[1], tw[2], tw[3]);
+        cmul_vc4(v[5], v[6], v[7], v[8], tw[4], tw[5], tw[6], tw[7]);
+        cmul_vc4(v[9], v[10], v[11], v[12], tw[8], tw[9], tw[10], tw[11]);
+        cmul_vc3(v[13], v[14], v[15], tw[12], tw[13], tw[14]);
     };
     auto x4 = [&](Fr& f) {
 #pragma unroll
@@ -762,7 +760,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
         m3(A, mkA, mnA, m512A);   GL2_LAND(Bf.v); x3(A);
         if (fn < nfr) load_mag(mkA, mnA, m512A, fn);
         GL_STAMP(sb + 3);
-        m3(Bf, mkB, mnB, m512B);  GL2_LAND(A.v);  x3(Bf);
+        m3(Bf, mkB, mnB, m512B);  ld_T2();  GL2_LAND(A.v);  x3(Bf);
         if (fn < nfr) load_mag(mkB, mnB, m512B, min(fn + GL_WAVES, nfr - 1));
         GL_STAMP(sb + 4);
         m2i(A);  GL2_LAND(Bf.v); x4(A);
