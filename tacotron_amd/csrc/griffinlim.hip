@@ -40,7 +40,8 @@ __device__ __forceinline__ float gl_mag_one(float lin, float min_db, float ref_d
 
 __global__ void gl_mag_kernel(const float* __restrict__ lin, float* __restrict__ mag, size_t n, float min_db,
                               float ref_db, float power) {
-    const size_t n4 = n / 4;
+    // (four at a time only when both pointers are 16-byte aligned: a caller may hand in a row slice of a larger tensor)
+    const size_t n4 = ((reinterpret_cast<size_t>(lin) | reinterpret_cast<size_t>(mag)) & 15) ? 0 : n / 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     for (size_t i = i0; i < n4; i += stride) {
         const float4 v = reinterpret_cast<const float4*>(lin)[i];
