@@ -1002,11 +1002,43 @@ void launch_gl_ola_norm(const GLPlan& p, const float* frames, float* wav, int B,
     if (tm) tm->end(KK_GL_OLA, s);
 }
 
+// the same sums (same order per sample) four samples a thread: hop and window multiples of 4, so four consecutive
+// samples starting at a multiple of 4 are covered by the same frames and every access is a 16-byte one
+__global__ void gl_ola4_kernel(const float* __restrict__ frames, float* __restrict__ wav, int B, int T, int hop, int win) {
+    const long L = (long)(T - 1) * hop + win;
+    const int nover = (win + hop - 1) / hop;
+    const long total4 = (long)B * L / 4;
+    for (long i4 = blockIdx.x * (long)blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
+        const long i = 4 * i4;
+        const int b = (int)(i / L);
+        const int g = (int)(i - (long)b * L);
+        const int mhi = min(T - 1, g / hop);
+        const int mlo = max(0, g / hop - (nover - 1));
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int m2 = mlo; m2 <= mhi; ++m2) {
+            const int off = g - hop * m2;
+            if (off < win) {
+                const float4 v = *reinterpret_cast<const float4*>(frames + ((long)b * T + m2) * win + off);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        *reinterpret_cast<float4*>(wav + i) = acc;
+    }
+}
+
 void launch_gl_ola(const GLPlan& p, const float* frames, float* wav, int B, int T, hipStream_t s, Timing* tm) {
     if (tm) tm->begin(KK_GL_OLA, s);
-    const long total = (long)B * ((long)(T - 1) * p.hop + p.win);
-    const int blocks = (int)std::min<long>(4096, (total + 255) / 256);
-    hipLaunchKernelGGL(gl_ola_kernel, dim3(blocks), dim3(256), 0, s, frames, wav, B, T, p.hop, p.win);
+    const long L = (long)(T - 1) * p.hop + p.win;
+    const long total = (long)B * L;
+    const bool vec = p.hop % 4 == 0 && p.win % 4 == 0 && L % 4 == 0 &&
+                     ((reinterpret_cast<size_t>(frames) | reinterpret_cast<size_t>(wav)) & 15) == 0;
+    if (vec) {
+        const int blocks = (int)std::min<long>(4096, (total / 4 + 255) / 256);
+        hipLaunchKernelGGL(gl_ola4_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, s, frames, wav, B, T, p.hop, p.win);
+    } else {
+        const int blocks = (int)std::min<long>(4096, (total + 255) / 256);
+        hipLaunchKernelGGL(gl_ola_kernel, dim3(blocks), dim3(256), 0, s, frames, wav, B, T, p.hop, p.win);
+    }
     if (tm) tm->end(KK_GL_OLA, s);
 }
 
