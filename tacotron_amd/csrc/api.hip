@@ -1157,14 +1157,16 @@ static int gl_impl(taco_ctx* c, const float* linear, int B, int T, int iters, fl
         float* a0 = fa + r0 * hp.win_length;
         float* a1 = fb + r0 * hp.win_length;
         const float* mg = mag + r0 * hp.num_freq;
-        launch_gl_iter(p, a0, mg, a0, nb, T, 1, st, t);     // y0 = istft(mag, zero phase) (audio.py:191)
+        int state = 0;                                      // what `cur` holds: frames, or run records (kernels.h)
+        launch_gl_iter(p, a0, mg, a0, nb, T, 1, st, t, false, nullptr, &state);   // y0 = istft(mag, zero phase) (audio.py:191)
         float* cur = a0;
         float* nxt = a1;
         for (int i = 0; i < iters; ++i) {                   // audio.py:192-195
-            launch_gl_iter(p, cur, mg, nxt, nb, T, 0, st, t);
+            launch_gl_iter(p, cur, mg, nxt, nb, T, 0, st, t, false, nullptr, &state);
             std::swap(cur, nxt);
         }
-        launch_gl_ola(p, cur, wav + (size_t)b0 * ((size_t)(T - 1) * hp.hop_length + hp.win_length), nb, T, st, t);
+        launch_gl_ola(p, cur, wav + (size_t)b0 * ((size_t)(T - 1) * hp.hop_length + hp.win_length), nb, T, st, t,
+                      state);
     };
     // An iteration of the whole batch is one launch that has to drain before the next may start: with workgroups that
     // live for ~25 us and only four rounds of them per launch, the chip idles for a good part of every launch's last
@@ -1308,14 +1310,15 @@ extern "C" int taco_griffin_lim_noalloc(taco_handle h, const float* linear, int3
     if (!cv.ok()) return fail("taco_griffin_lim_noalloc: static scratch too small for these hparams");
     GLPlan p{hp.n_fft, hp.hop_length, hp.win_length, hp.num_freq, h->twiddle, h->window, h->gl_image};
     launch_gl_mag(linear, mag, M * hp.num_freq, hp.min_level_db, hp.ref_level_db, hp.power, s, nullptr);
-    launch_gl_iter(p, fa, mag, fa, B, T, 1, s, nullptr);
+    int state = 0;
+    launch_gl_iter(p, fa, mag, fa, B, T, 1, s, nullptr, false, nullptr, &state);
     float* cur = fa;
     float* nxt = fb;
     for (int i = 0; i < iters; ++i) {
-        launch_gl_iter(p, cur, mag, nxt, B, T, 0, s, nullptr);
+        launch_gl_iter(p, cur, mag, nxt, B, T, 0, s, nullptr, false, nullptr, &state);
         std::swap(cur, nxt);
     }
-    launch_gl_ola(p, cur, wav, B, T, s, nullptr);
+    launch_gl_ola(p, cur, wav, B, T, s, nullptr, state);
     return check_launch("taco_griffin_lim_noalloc");
 }
 

@@ -408,7 +408,22 @@ struct GL2Frame {
     float* out;              // its row of frames_out
 };
 
-template <int WIN, int HOP>
+// LDS-only workgroup barrier: waits for the wave's LDS operations, not for its global loads and stores in flight (the
+// magnitudes of the next pair, the record stores), which __syncthreads() would drain too
+__device__ __forceinline__ void gl_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// State between iterations. SIN / SOUT = false: the windowed frames of the previous iteration, [B*T][WIN] (every sample
+// four times: 4.8 KB per frame written and read). true: RUN RECORDS, the overlap-added signal itself plus what the
+// neighbouring runs need to finish their sums in the same order, per run of `run` frames
+//   [H0: WIN-HOP | H1: WIN-2 HOP | H2: WIN-3 HOP | SUMS: HOP run]  (2 (WIN-HOP) + HOP run floats)
+// H_f = frame f of the run over the run's first WIN-HOP samples (which frames of the previous run also cover), raw;
+// SUMS[s - (WIN-HOP)] = sum of the RUN'S OWN frames covering sample s >= WIN-HOP of the run, in ascending frame order
+// (complete for s < HOP nfr; for the last WIN-HOP samples, which frames of the next run also cover, the prefix of the
+// sample's sum). The next iteration forms y[s] = ((a + b) + c) + d with a = the previous run's prefix (head samples) or
+// the own sum, and b, c, d = own / next run's raw head frames in ascending order or 0: the very additions of the
+// frame-state gather, in the same order, so both states give the same bits (and so do runs of 8 and of 16 frames).
+// (1.3 KB per frame written, 2.3 KB read at run = 16.)
+template <int WIN, int HOP, bool SIN, bool SOUT>
 __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __restrict__ frames_in,
                                                                 const float* __restrict__ mag,
                                                                 float* __restrict__ frames_out,
@@ -417,7 +432,11 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
     extern __shared__ __attribute__((aligned(16))) unsigned char gl_smem[];
     static_assert(WIN % 4 == 0 && HOP % 4 == 0 && WIN % HOP == 0 && WIN / 2 <= 640 && WIN / 2 > 576,
                   "gl_iter2 is written for windows of 1154..1280 samples (ten live inputs per lane)");
+    static_assert(WIN == 4 * HOP, "run records are laid out for four covering frames per sample");
     constexpr int HALF = WIN / 2;
+    constexpr int HEAD = WIN - HOP;                      // samples at a run's start / end shared with the neighbour run
+    constexpr int HOFF1 = HEAD, HOFF2 = 2 * HEAD - HOP;  // H1, H2 in a record; SUMS[s - HEAD] sits at 2 HEAD + s - HEAD
+    const int RS = 2 * HEAD + HOP * run;                 // floats per record
     const int seg_cap = (run - 1) * HOP + WIN;
     float* yseg = reinterpret_cast<float*>(gl_smem);
     float* win_s = yseg + ((seg_cap + 3) & ~3);
@@ -426,8 +445,13 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
     const cplx* T3 = tw_s + FFT_T2;
     cplx* wk_s = tw_s + FFT_TW;
     cplx* fft_s = wk_s + FFT_N / 2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (the wave number as a scalar: the wave's buffer, its frames and their rows are then scalar values too)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane_ = lane;
     cplx* lds = fft_s + wave * GL2_LDS;
+    // SOUT: partial sums of the samples [8 HOP, 8 HOP + HEAD) of the run, which frames of both rounds of a 16-frame run
+    // cover (the second round's inputs still sit in yseg at those places when the first round's outputs arrive)
+    float* side_s = reinterpret_cast<float*>(fft_s + GL_WAVES * GL2_LDS);
 
     // Workgroup i is placed on XCD i % 8: the runs are dealt out so that the workgroups of one XCD hold a contiguous
     // range of runs, and neighbouring runs (which read three frames of each other's range) meet in that XCD's L2.
@@ -437,10 +461,12 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
         wg = x * per + min(x, rem) + (wg >> 3);
     }
     const int b = wg / runs_per_utt;
-    const int m0 = (wg - b * runs_per_utt) * run;
+    const int ru = wg - b * runs_per_utt;                // the run's index in its utterance
+    const int m0 = ru * run;
     const int nfr = min(run, T - m0);
     const long fb = (long)b * T;
     typedef float f4v __attribute__((ext_vector_type(4)));
+    (void)RS; (void)side_s; (void)ru;
 
     GL_STAMP(0);
     // target magnitudes of the lane's bin pairs (k, 1024 - k), k = lane + 64 j, for the two frames of the wave's first
@@ -463,15 +489,19 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
             default: return 448 - lane;
         }
     };
+    // (through a buffer resource over the run's rows: a 32-bit lane offset + the frame's row as the scalar offset,
+    // instead of sixteen 64-bit lane addresses kept alive from pair to pair)
+    const __amdgpu_buffer_rsrc_t mag_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(mag + (fb + m0) * nbins), 0, nfr * nbins * 4, 0x00020000);
     auto load_mag = [&](float (&mk)[8], float (&mn)[8], float& m512, int fi) {
-        const float* mg = mag + (fb + m0 + fi) * nbins;
+        const unsigned row = (unsigned)fi * (unsigned)nbins * 4u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = pair_bin(j);
-            mk[j] = mg[k];
-            mn[j] = mg[FFT_N - k];
+            const unsigned k = (unsigned)pair_bin(j);
+            mk[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mag_rs, 4u * k, row, 0));
+            mn[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mag_rs, 4u * (FFT_N - k), row, 0));
         }
-        m512 = mg[FFT_N / 2];
+        m512 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mag_rs, 4u * (FFT_N / 2), row, 0));
     };
     load_mag(mkA, mnA, m512A, min(wave, nfr - 1));
     load_mag(mkB, mnB, m512B, min(wave + GL_WAVES, nfr - 1));
@@ -504,7 +534,43 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
         constexpr int NOVER = WIN / HOP;
         static_assert(NOVER == 4, "the gather is written for four covering frames");
         const float* fu = frames_in + fb * WIN;
-        if (m0 >= NOVER - 1 && m0 + nfr + NOVER - 2 <= T - 1) {
+        if constexpr (SIN) {
+            // from run records: a = the previous run's prefix sum (head samples, 0 for the first run) or the own sum,
+            // then the raw head frames of the own (head samples) or the next run (tail samples) in ascending order
+            const float* rec = frames_in + ((long)b * runs_per_utt + ru) * RS;
+            const bool has_prev = ru > 0, has_next = ru + 1 < runs_per_utt;
+            constexpr int STEPS = ((GL_RUN - 1) * HOP + WIN + 4 * GL_THREADS - 1) / (4 * GL_THREADS);
+            f4v ga[STEPS], gb[STEPS], gc[STEPS], gd[STEPS];
+            const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                const int i = 4 * (tid + GL_THREADS * st);
+                ga[st] = gb[st] = gc[st] = gd[st] = zero4;
+                if (i < seg) {
+                    const float* hp = nullptr;           // record whose raw head frames cover the sample
+                    int j = i;                           // ... and the sample's offset in that record's head
+                    if (i < HEAD) {
+                        if (has_prev) ga[st] = *reinterpret_cast<const f4v*>(rec - RS + HEAD + HOP * run + i);
+                        hp = rec;
+                    } else {
+                        ga[st] = *reinterpret_cast<const f4v*>(rec + HEAD + i);
+                        j = i - HOP * nfr;
+                        if (j >= 0 && has_next) hp = rec + RS;
+                    }
+                    if (hp) {
+                        gb[st] = *reinterpret_cast<const f4v*>(hp + j);
+                        if (j >= HOP) gc[st] = *reinterpret_cast<const f4v*>(hp + HOFF1 + j - HOP);
+                        if (j >= 2 * HOP) gd[st] = *reinterpret_cast<const f4v*>(hp + HOFF2 + j - 2 * HOP);
+                    }
+                }
+            }
+            store_tables();
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                const int i = 4 * (tid + GL_THREADS * st);
+                if (i < seg) *reinterpret_cast<f4v*>(yseg + i) = ((ga[st] + gb[st]) + gc[st]) + gd[st];
+            }
+        } else if (m0 >= NOVER - 1 && m0 + nfr + NOVER - 2 <= T - 1) {
             const float* base = fu + (long)(m0 - (NOVER - 1)) * WIN + HOP * (NOVER - 1);   // frame q-3 at offset r + 3 HOP
             // every load of the thread is issued before the first sum: one memory round trip for the whole segment
             // (the registers are free here, the transform's working set is not live yet)
@@ -743,38 +809,172 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
         }
     };
 
+    // SOUT: where the sum of sample s (run coordinates, s >= HEAD) is built up
+    auto dest = [&](int s) {
+        return (unsigned)(s - 2 * GL_WAVES * HOP) < (unsigned)HEAD ? side_s + (s - 2 * GL_WAVES * HOP) : yseg + s;
+    };
+    // pass 1 backwards, then the windowed frame goes three ways. (1) Its last HOP samples, to which it is the first
+    // contributor of the run: plain store at dest (every input of this round has been read: barrier after a1).
+    // (2) Its first HEAD samples: into the wave's exchange buffer (dead after the last exchange; slot = A / B), from
+    // where the pass below adds them in frame order. (3) MAYHEAD (frames 0..2 of the run): what falls into the run's
+    // first HEAD samples goes to the record raw instead (the sums there start with the previous run's frames).
+    auto m7s = [&](Fr& f, int fidx, int slot, bool store, bool mayhead) {
+        dft16<true>(f.v);
+        if (!store) return;
+        const float sc = 0.5f / FFT_N;
+        // (the lane's addresses below are formed here, from a copy of the lane number the compiler cannot see through:
+        // as loop invariants they would be computed once and held in registers over the whole transform)
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));
+        float* pv = reinterpret_cast<float*>(lds) + slot * HEAD;
+        float* rec = frames_out + ((long)b * runs_per_utt + ru) * RS;
+        if (mayhead && fidx < 3) {
+            float* hraw = rec + (fidx == 0 ? 0 : (fidx == 1 ? HOFF1 : HOFF2));
+            const int th = HEAD - HOP * fidx;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int c = lane + 64 * i, o = 2 * c;
+                if (i < 9 || c < HALF) {
+                    const float2 wv = *reinterpret_cast<const float2*>(win_s + o);
+                    const float2 val = make_float2(f.v[i].x * sc * wv.x, f.v[i].y * sc * wv.y);
+                    if (o < th) *reinterpret_cast<float2*>(hraw + o) = val;
+                    else if (o < HEAD) *reinterpret_cast<float2*>(pv + o) = val;
+                    else *reinterpret_cast<float2*>(dest(HOP * fidx + o)) = val;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int c = lane + 64 * i, o = 2 * c;
+                if (i < 9 || c < HALF) {
+                    const float2 wv = *reinterpret_cast<const float2*>(win_s + o);
+                    const float2 val = make_float2(f.v[i].x * sc * wv.x, f.v[i].y * sc * wv.y);
+                    if (128 * i + 126 < HEAD) *reinterpret_cast<float2*>(pv + o) = val;
+                    else if (128 * i >= HEAD) *reinterpret_cast<float2*>(dest(HOP * fidx + o)) = val;
+                    else *reinterpret_cast<float2*>(o < HEAD ? pv + o : dest(HOP * fidx + o)) = val;
+                }
+            }
+        }
+    };
+    // after a round of eight frames F0..F1-1 (all waves' m7s behind a barrier): the samples they reach, four a thread.
+    // acc = what the sample's first contributor stored (or the first round left), + the round's other contributions
+    // in ascending frame order; complete sums (and the run's last HEAD samples' prefixes) go to the record, the
+    // samples the next round adds to go back to LDS.
+    auto pass = [&](int rd) {
+        const int F0 = 2 * GL_WAVES * rd, F1 = min(F0 + 2 * GL_WAVES, nfr);
+        const int lo = rd ? HOP * F0 : HEAD, hi = HOP * F1 + HEAD;
+        float* rec = frames_out + ((long)b * runs_per_utt + ru) * RS;
+        const float* pbase = reinterpret_cast<const float*>(fft_s);
+        // a wave takes whole hops of samples (wave, wave + 4, ...): which frames contribute, whether the sums are
+        // complete and where everything lies is then the same for all its lanes (scalar arithmetic and branches), and
+        // a lane is left with one address offset: 75 groups of four samples per hop = the 64 lanes + a trip of 11
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));
+        // (all reads of the wave's hops are issued before the first sum: beside a transforming neighbour an LDS round
+        // trip takes the better part of a microsecond; an absent contribution reads the sample's own place instead)
+        constexpr int NSEG = (2 * GL_WAVES * HOP + HEAD) / HOP, NS = (NSEG + GL_WAVES - 1) / GL_WAVES;
+        constexpr int NT = (HOP / 4 + 63) / 64;
+        f4v a[NS][NT], c[NS][NT][3];
+#pragma unroll
+        for (int g = 0; g < NS; ++g) {
+            const int s0 = min(lo + HOP * (wave + GL_WAVES * g), hi - HOP);
+            const int q = s0 / HOP;
+            const float* dp = dest(s0);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int fq = q - 2 + d;
+                const bool ok = fq >= F0 && fq < F1;
+                const float* cp = ok ? pbase + (fq & 3) * (2 * GL2_LDS) + ((fq >> 2) & 1) * HEAD + (s0 - HOP * fq) : dp;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int off = min(4 * (lane + 64 * t), HOP - 4);
+                    c[g][t][d] = *reinterpret_cast<const f4v*>(cp + off);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a[g][t] = *reinterpret_cast<const f4v*>(dp + min(4 * (lane + 64 * t), HOP - 4));
+        }
+#pragma unroll
+        for (int g = 0; g < NS; ++g) {
+            const int s0 = lo + HOP * (wave + GL_WAVES * g);
+            if (s0 < hi) {
+                const int q = s0 / HOP;
+                const bool fin = q < F1 || F1 == nfr;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int off = 4 * (lane + 64 * t);
+                    f4v acc = a[g][t];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const int fq = q - 2 + d;
+                        if (fq >= F0 && fq < F1) acc += c[g][t][d];
+                    }
+                    if (off < HOP) {
+                        if (fin) *reinterpret_cast<f4v*>(rec + HEAD + s0 + off) = acc;
+                        else *reinterpret_cast<f4v*>(dest(s0) + off) = acc;
+                    }
+                }
+            }
+        }
+    };
+
     // frames of this wave: wave, wave + 4, ...; two at a time, half a stage apart: while one frame's exchange is in
     // flight the other frame computes. A last, single frame runs as a pair with itself (the copy is not stored).
-    for (int fi = wave; fi < nfr; fi += 2 * GL_WAVES) {
-        Fr A, Bf;
-        const bool pair = fi + GL_WAVES < nfr;
-        s0_load(A, fi);
-        s0_load(Bf, pair ? fi + GL_WAVES : fi);
-        const int sb = 4 + 10 * (fi >= 2 * GL_WAVES);
-        (void)sb;
-        GL_STAMP(sb);
-        a1(A, Bf);
-        d1(A);   x_pass1(A);  ld_T2();
-        d1(Bf);  GL2_LAND(A.v);  x_pass1(Bf);
-        GL_STAMP(sb + 1);
-        m2f(A);  dft16<false>(A.v);  GL2_LAND(Bf.v); x_pass2(A);
-        m2f(Bf); ld_T3(); dft16<false>(Bf.v); GL2_LAND(A.v);  x_pass2(Bf);
-        GL_STAMP(sb + 2);
-        const int fn = fi + 2 * GL_WAVES;               // the wave's next pair
-        m3(A, mkA, mnA, m512A);   GL2_LAND(Bf.v); x3(A);
-        if (fn < nfr) load_mag(mkA, mnA, m512A, fn);
-        GL_STAMP(sb + 3);
-        m3(Bf, mkB, mnB, m512B);  ld_T2();  GL2_LAND(A.v);  x3(Bf);
-        if (fn < nfr) load_mag(mkB, mnB, m512B, min(fn + GL_WAVES, nfr - 1));
-        GL_STAMP(sb + 4);
-        m2i(A);  GL2_LAND(Bf.v); x4(A);
-        GL_STAMP(sb + 5);
-        m2i(Bf); GL2_LAND(A.v);  x4(Bf);
-        GL_STAMP(sb + 6);
-        m7(A, true);
-        GL2_LAND(Bf.v);
-        m7(Bf, pair);
-        GL_STAMP(sb + 7);
+    // SOUT: a round (the workgroup's next eight frames) is bracketed by workgroup barriers, so every wave takes every
+    // round, with or without a frame of its own in it.
+    const int nrounds = SOUT ? (nfr + 2 * GL_WAVES - 1) / (2 * GL_WAVES) : 1;
+    for (int rd = 0; rd < nrounds; ++rd) {
+        for (int fi = wave + (SOUT ? 2 * GL_WAVES * rd : 0); fi < (SOUT ? min(nfr, 2 * GL_WAVES * (rd + 1)) : nfr);
+             fi += 2 * GL_WAVES) {
+            Fr A, Bf;
+            const bool pair = fi + GL_WAVES < nfr;
+            s0_load(A, fi);
+            s0_load(Bf, pair ? fi + GL_WAVES : fi);
+            const int sb = 4 + 10 * (fi >= 2 * GL_WAVES);
+            (void)sb;
+            GL_STAMP(sb);
+            a1(A, Bf);
+            if constexpr (SOUT) gl_lds_barrier();           // (B1) every input of the round is in registers
+            d1(A);   x_pass1(A);  ld_T2();
+            d1(Bf);  GL2_LAND(A.v);  x_pass1(Bf);
+            GL_STAMP(sb + 1);
+            m2f(A);  dft16<false>(A.v);  GL2_LAND(Bf.v); x_pass2(A);
+            m2f(Bf); ld_T3(); dft16<false>(Bf.v); GL2_LAND(A.v);  x_pass2(Bf);
+            GL_STAMP(sb + 2);
+            const int fn = fi + 2 * GL_WAVES;               // the wave's next pair
+            m3(A, mkA, mnA, m512A);   GL2_LAND(Bf.v); x3(A);
+            if (fn < nfr) load_mag(mkA, mnA, m512A, fn);
+            GL_STAMP(sb + 3);
+            m3(Bf, mkB, mnB, m512B);  ld_T2();  GL2_LAND(A.v);  x3(Bf);
+            if (fn < nfr) load_mag(mkB, mnB, m512B, min(fn + GL_WAVES, nfr - 1));
+            GL_STAMP(sb + 4);
+            m2i(A);  GL2_LAND(Bf.v); x4(A);
+            GL_STAMP(sb + 5);
+            m2i(Bf); GL2_LAND(A.v);  x4(Bf);
+            GL_STAMP(sb + 6);
+            if constexpr (SOUT) {
+                // (A's slot of the exchange buffer is written behind B's reads of it: the LDS takes a wave's
+                // operations in order)
+                m7s(A, fi, 0, true, true);
+                GL2_LAND(Bf.v);
+                m7s(Bf, fi + GL_WAVES, 1, pair, false);
+            } else {
+                m7(A, true);
+                GL2_LAND(Bf.v);
+                m7(Bf, pair);
+            }
+            GL_STAMP(sb + 7);
+        }
+        if constexpr (SOUT) {
+            // a wave without a frame in this round (a short last run) still owes the round's barriers
+            if (wave + 2 * GL_WAVES * rd >= nfr) gl_lds_barrier();      // (B1)
+            gl_lds_barrier();                                           // (B2) the round's contributions are in LDS
+            GL_STAMP(24 + 3 * rd);
+            pass(rd);
+            GL_STAMP(25 + 3 * rd);
+            if (rd + 1 < nrounds) gl_lds_barrier();                     // (B3) before the buffers are written again
+            GL_STAMP(26 + 3 * rd);
+        }
     }
 }
 
@@ -788,8 +988,10 @@ void gl_prepare_device() {
                         gl_iter_kernel<true, 1200, 300>})
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iter2_kernel<1200, 300>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (auto* k : {gl_iter2_kernel<1200, 300, false, false>, gl_iter2_kernel<1200, 300, false, true>,
+                        gl_iter2_kernel<1200, 300, true, true>})
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
         attr_set[dev] = true;
     }
 }
@@ -828,8 +1030,32 @@ std::vector<float> gl_lds_image(const std::vector<float>& tw, const std::vector<
     return img;
 }
 
+// Frames per workgroup of gl_iter2_kernel for a job of B utterances of T frames: whole pairs per wave only (8 or 16
+// frames); the shorter run when it does not cost another round of workgroups over the chip's 512 places (two per CU):
+// a workgroup lives for about one gather plus one transform time per pair, and a gather takes about as long as a pair.
+static int gl2_run(int B, int T) {
+    if (const char* e = getenv("TACO_GL_RUN")) {         // experiments: 8 or 16
+        const int r = atoi(e);
+        if (r == 8 || r == 16) return r;
+    }
+    const long slots = 512;
+    auto rounds = [&](int r) { return ((long)B * ((T + r - 1) / r) + slots - 1) / slots; };
+    return rounds(8) * 2 <= rounds(16) * 3 ? 8 : GL_RUN;
+}
+// Run records need every run to hold the three raw head frames: a last run of one or two frames keeps the frame state
+// (same bits either way, so the choice may depend on the batch). They pay when the launch is bound by what it moves,
+// not when its few workgroups have a CU each and the round barriers only lengthen them: GL2_RECORDS_MIN_GRID.
+// TACO_GL_FRAME_STATE=1 keeps the frame state always, =0 takes records whenever the geometry allows (tests compare).
+constexpr long GL2_RECORDS_MIN_GRID = 257;
+static bool gl2_records_ok(int T, int run, long grid) {
+    const int last = T % run;
+    if (!(last == 0 || last >= 3)) return false;
+    if (const char* e = getenv("TACO_GL_FRAME_STATE")) return atoi(e) == 0;
+    return grid >= GL2_RECORDS_MIN_GRID;
+}
+
 void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, float* frames_out, int B, int T,
-                    int first, hipStream_t s, Timing* tm, bool librosa, const float* phase_u) {
+                    int first, hipStream_t s, Timing* tm, bool librosa, const float* phase_u, int* state) {
     if (tm) tm->begin(KK_GL_ITER, s);
     // frames per workgroup: as many as keep the y segment within ~24 KB of LDS (2 workgroups per CU and more)
     int run = GL_RUN;
@@ -842,24 +1068,32 @@ void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, f
     // small jobs: shorter runs (down to one frame, or one pair of frames, per wave) until the grid covers the chip
     // twice; the overlap-add order per sample does not depend on the run length, so results are bit-identical
     if (two) {
-        // whole pairs per wave only (8 or 16 frames); the shorter run when it does not cost another round of
-        // workgroups over the chip's 512 places (two per CU): a workgroup lives for about one gather plus one
-        // transform time per pair, and a gather takes about as long as a pair
-        const long slots = 512;
-        auto rounds = [&](int r) { return ((long)B * ((T + r - 1) / r) + slots - 1) / slots; };
-        if (rounds(8) * 2 <= rounds(16) * 3) run = 8;
+        run = gl2_run(B, T);
     } else {
         while (run > GL_WAVES && (long)B * ((T + run - 1) / run) < 512) run -= GL_WAVES;
     }
     const int runs_per_utt = (T + run - 1) / run;
     gl_prepare_device();
     const dim3 grid((unsigned)(B * runs_per_utt));
+    const int sin = state ? *state : 0;                  // what frames_in holds: 0 = frames, 1 = run records
     if (two) {
+        // the state written: run records when the caller can take them (it passes `state`) and the geometry allows
+        const int sout = state && gl2_records_ok(T, run, (long)B * runs_per_utt) ? 1 : 0;
         const size_t lds = (size_t)(((run - 1) * p.hop + p.win + 3) & ~3) * 4 + (size_t)p.win * 4 +
-                           (size_t)(FFT_TW + FFT_N / 2 + GL_WAVES * GL2_LDS) * sizeof(cplx);
-        hipLaunchKernelGGL((gl_iter2_kernel<1200, 300>), grid, dim3(GL_THREADS), lds, s, frames_in, mag, frames_out,
-                           p.lds_image, B, T, p.nbins, run, runs_per_utt);
+                           (size_t)(FFT_TW + FFT_N / 2 + GL_WAVES * GL2_LDS) * sizeof(cplx) +
+                           (sout ? (size_t)(p.win - p.hop) * 4 : 0);
+        auto* kern = sin ? gl_iter2_kernel<1200, 300, true, true>
+                         : (sout ? gl_iter2_kernel<1200, 300, false, true> : gl_iter2_kernel<1200, 300, false, false>);
+        // (records in -> records out always: eligibility depends on T and the run only, which a chain does not change)
+        hipLaunchKernelGGL(kern, grid, dim3(GL_THREADS), lds, s, frames_in, mag, frames_out, p.lds_image, B, T,
+                           p.nbins, run, runs_per_utt);
+        if (state) *state = sin ? 1 : sout;
     } else {
+        if (sin) {                                       // cannot happen within a chain (same B, T, flavour throughout)
+            fprintf(stderr, "taco: launch_gl_iter: run records handed to a kernel that reads frames\n");
+            abort();
+        }
+        if (state) *state = 0;
         const size_t lds = (size_t)((((run - 1) * p.hop + p.win + 3) & ~3) + ((p.win + 3) & ~3)) * 4 +
                            (size_t)(FFT_TW + FFT_N / 2 + GL_WAVES * FFT_LDS) * sizeof(cplx);
         auto* kern = librosa ? (dflt ? gl_iter_kernel<true, 1200, 300> : gl_iter_kernel<true, 0, 0>)
@@ -1026,8 +1260,61 @@ __global__ void gl_ola4_kernel(const float* __restrict__ frames, float* __restri
     }
 }
 
-void launch_gl_ola(const GLPlan& p, const float* frames, float* wav, int B, int T, hipStream_t s, Timing* tm) {
+// The signal from run records (gl_iter2_kernel): a sample is the own sum of the run whose SUMS hold it (+ the next
+// run's raw head frames where it lies in that run's last WIN-HOP samples), or, for the utterance's first WIN-HOP
+// samples, the first run's raw head frames alone: the additions of the iteration's gather, i.e. of gl_ola_kernel.
+template <int WIN, int HOP, bool VEC>
+__global__ void gl_ola_rec_kernel(const float* __restrict__ recs, float* __restrict__ wav, int B, int T, int run,
+                                  int runs_per_utt) {
+    constexpr int HEAD = WIN - HOP, HOFF1 = HEAD, HOFF2 = 2 * HEAD - HOP;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const int RS = 2 * HEAD + HOP * run;
+    const long L = (long)(T - 1) * HOP + WIN;
+    const long total4 = (long)B * L / 4;
+    for (long i4 = blockIdx.x * (long)blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
+        const long i = 4 * i4;
+        const int b = (int)(i / L);
+        const int g = (int)(i - (long)b * L);
+        const float* ur = recs + (long)b * runs_per_utt * RS;
+        f4v acc = {0.f, 0.f, 0.f, 0.f};
+        const float* hp = nullptr;
+        int j = g;
+        if (g < HEAD) {
+            hp = ur;
+        } else {
+            const int ru = min((g - HEAD) / (HOP * run), runs_per_utt - 1);
+            const int sidx = g - HOP * run * ru;                      // >= HEAD
+            const float* rec = ur + (long)ru * RS;
+            acc = *reinterpret_cast<const f4v*>(rec + HEAD + sidx);
+            j = sidx - HOP * run;                                     // >= 0: the run is full and the sample in its tail
+            if (j >= 0 && ru + 1 < runs_per_utt) hp = rec + RS;
+        }
+        if (hp) {
+            acc += *reinterpret_cast<const f4v*>(hp + j);
+            if (j >= HOP) acc += *reinterpret_cast<const f4v*>(hp + HOFF1 + j - HOP);
+            if (j >= 2 * HOP) acc += *reinterpret_cast<const f4v*>(hp + HOFF2 + j - 2 * HOP);
+        }
+        if (VEC) *reinterpret_cast<f4v*>(wav + i) = acc;
+        else {
+            wav[i] = acc.x; wav[i + 1] = acc.y; wav[i + 2] = acc.z; wav[i + 3] = acc.w;
+        }
+    }
+}
+
+void launch_gl_ola(const GLPlan& p, const float* frames, float* wav, int B, int T, hipStream_t s, Timing* tm,
+                   int state) {
     if (tm) tm->begin(KK_GL_OLA, s);
+    if (state) {                                       // run records (default geometry only, see launch_gl_iter)
+        const int run = gl2_run(B, T);
+        const int runs_per_utt = (T + run - 1) / run;
+        const long L4 = (long)B * ((long)(T - 1) * p.hop + p.win) / 4;
+        const int blocks = (int)std::max<long>(1, std::min<long>(4096, (L4 + 255) / 256));
+        auto* kern = (reinterpret_cast<size_t>(wav) & 15) == 0 ? gl_ola_rec_kernel<1200, 300, true>
+                                                               : gl_ola_rec_kernel<1200, 300, false>;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, frames, wav, B, T, run, runs_per_utt);
+        if (tm) tm->end(KK_GL_OLA, s);
+        return;
+    }
     const long L = (long)(T - 1) * p.hop + p.win;
     const long total = (long)B * L;
     const bool vec = p.hop % 4 == 0 && p.win % 4 == 0 && L % 4 == 0 &&

@@ -173,11 +173,17 @@ void launch_gl_mag(const float* lin, float* mag, size_t n, float min_db, float r
 // frames_in/out [B*T][win]; first != 0: inverse of (mag, zero phase) only. librosa: the numpy/librosa flavour of the
 // loop (normalised, trimmed, reflect-padded signal between iterations; first synthesis from the phases
 // exp(2 pi i phase_u), phase_u [B*T][nbins] or null = zero phase).
+// state: null = the loop's state is the frames, in and out. Otherwise *state says what frames_in holds (0 = frames,
+// 1 = run records, the overlap-added signal per run of frames as gl_iter2_kernel lays it out, which fits the same
+// buffer) and receives what frames_out holds after the launch; hand it from launch to launch and to launch_gl_ola.
+// All launches of a chain must be given the same B and T.
 void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, float* frames_out, int B, int T,
-                    int first, hipStream_t s, Timing* tm, bool librosa = false, const float* phase_u = nullptr);
+                    int first, hipStream_t s, Timing* tm, bool librosa = false, const float* phase_u = nullptr,
+                    int* state = nullptr);
 std::vector<float> gl_lds_image(const std::vector<float>& twiddle, const std::vector<float>& window);
 void gl_prepare_device();   // per-device kernel attributes of gl_iter (idempotent)
-void launch_gl_ola(const GLPlan& p, const float* frames, float* wav, int B, int T, hipStream_t s, Timing* tm);
+void launch_gl_ola(const GLPlan& p, const float* frames, float* wav, int B, int T, hipStream_t s, Timing* tm,
+                   int state = 0);
 // librosa.istft's output: wav [B][hop (T-1)], window-sum-square normalised, n_fft/2 trimmed from both ends
 void launch_gl_ola_norm(const GLPlan& p, const float* frames, float* wav, int B, int T, hipStream_t s, Timing* tm);
 // Centred STFT analysis (librosa.stft of the pre-emphasised signal, tools/audio.py:37,119-134): wav [B, n] ->

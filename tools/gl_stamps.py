@@ -1,5 +1,5 @@
 """Diagnostic: where one workgroup of gl_iter2 spends its cycles (needs the -DGL_STAMPS build of the library):
-   TACO_LIB=tacotron_amd/libtaco_b_stamps.so python tools/gl_stamps.py [B]"""
+   TACO_LIB=tacotron_amd/libtaco_v_stamps.so (tools/build_variant.sh stamps -DGL_STAMPS -DGL_STAMP_WG=1016) python tools/gl_stamps.py [B]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tacotron_amd import _lib
@@ -20,5 +20,7 @@ for rep in range(3):
     idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]
     names += ['', ''] + ['p2.' + n for n in ('begin', 's1', 's2', 's3', 's4', 's5', 's6', 'end')]
     idx += [14, 15, 16, 17, 18, 19, 20, 21]
+    names += ['r1.B2', 'r1.pass', 'r1.B3', 'r2.B2', 'r2.pass', 'r2.end']
+    idx += [24, 25, 26, 27, 28, 29]
     names = [n for n in names if n]
     print(' '.join('%s %d' % (n, t[i] - t[0]) for n, i in zip(names, idx)), flush=True)
