@@ -452,6 +452,8 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
     // SOUT: partial sums of the samples [8 HOP, 8 HOP + HEAD) of the run, which frames of both rounds of a 16-frame run
     // cover (the second round's inputs still sit in yseg at those places when the first round's outputs arrive)
     float* side_s = reinterpret_cast<float*>(fft_s + GL_WAVES * GL2_LDS);
+    float* zero_s = side_s + WIN - HOP;                  // SOUT: four zeros (set before the first barrier)
+    if (SOUT && tid < 4) zero_s[tid] = 0.f;
 
     // Workgroup i is placed on XCD i % 8: the runs are dealt out so that the workgroups of one XCD hold a contiguous
     // range of runs, and neighbouring runs (which read three frames of each other's range) meet in that XCD's L2.
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
     const int nfr = min(run, T - m0);
     const long fb = (long)b * T;
     typedef float f4v __attribute__((ext_vector_type(4)));
-    (void)RS; (void)side_s; (void)ru;
+    (void)RS; (void)side_s; (void)ru; (void)zero_s;
 
     GL_STAMP(0);
     // target magnitudes of the lane's bin pairs (k, 1024 - k), k = lane + 64 j, for the two frames of the wave's first
@@ -668,26 +670,37 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
         }
     };
     auto d1 = [&](Fr& f) { dft16_fwd_in10(f.v); };
+    // The padded places fft_pad(j) = j + (j >> 4) of the exchange patterns, written as ONE lane base + a constant per
+    // element (the compiler, given fft_pad(lane + 64 i), forms a register per element instead: ~45 address registers
+    // held over the whole kernel and ~250 instructions to set them up):
+    //   fft_pad(lane + 64 i) = pr + 68 i, fft_pad(16 lane + c) = 17 lane + c, fft_pad(lane + 256 i) = pr + 272 i,
+    //   fft_pad(64 + lane + 256 i) = pr + 68 + 272 i, fft_pad(192 - lane + 256 i) = pm + 272 i, fft_pad(t3l + 256 i)
+    //   = pt + 272 i, fft_pad((lane >> 4) 256 + (lane & 15) + 16 c) = pb + 17 c   (checked for every lane, i, c)
+    cplx* const l_r = lds + lane + (lane >> 4);
+    cplx* const l_17 = lds + 17 * lane;
+    cplx* const l_b = lds + (lane >> 4) * 272 + (lane & 15);
+    cplx* const l_m = lds + (192 - lane) + ((192 - lane) >> 4);
     auto x_pass1 = [&](Fr& f) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) lds[fft_pad(16 * lane + c)] = f.v[c];
-        fft_load(f.v, lds, lane);
+        for (int c = 0; c < 16; ++c) l_17[c] = f.v[c];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) f.v[i] = l_r[68 * i];
     };
     // Pass 2 writes y2[(t - k) 16 + k + 16 c]; the radix-4 pass that follows reads butterfly t's inputs y2[t + 256 i].
     // Which four butterflies a lane takes is free: here t = l, 64 + l, 192 - l, 256 - l (lane 0: 0, 64, 192, 128), so
     // that the outputs X[t + 256 i'] of a lane contain BOTH members of each of its eight bin pairs (k, 1024 - k): the
     // split / re-phase / merge of the real transform then works on registers alone, with no partner exchange through
     // LDS before and after it, and the inverse transform runs the three passes backwards from the same registers.
+    cplx* const l_t = lds + t3l + (t3l >> 4);
     auto x_pass2 = [&](Fr& f) {
-        const int base = (lane >> 4) * 256 + (lane & 15);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) lds[fft_pad(base + 16 * c)] = f.v[c];
+        for (int c = 0; c < 16; ++c) l_b[17 * c] = f.v[c];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f.v[4 * i] = lds[fft_pad(lane + 256 * i)];
-            f.v[4 * i + 1] = lds[fft_pad(64 + lane + 256 * i)];
-            f.v[4 * i + 2] = lds[fft_pad(192 - lane + 256 * i)];
-            f.v[4 * i + 3] = lds[fft_pad(t3l + 256 * i)];
+            f.v[4 * i] = l_r[272 * i];
+            f.v[4 * i + 1] = l_r[68 + 272 * i];
+            f.v[4 * i + 2] = l_m[272 * i];
+            f.v[4 * i + 3] = l_t[272 * i];
         }
     };
     auto m2f = [&](Fr& f) {
@@ -768,14 +781,13 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
     auto x3 = [&](Fr& f) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            lds[fft_pad(lane + 256 * i)] = f.v[4 * i];
-            lds[fft_pad(64 + lane + 256 * i)] = f.v[4 * i + 1];
-            lds[fft_pad(192 - lane + 256 * i)] = f.v[4 * i + 2];
-            lds[fft_pad(t3l + 256 * i)] = f.v[4 * i + 3];
+            l_r[272 * i] = f.v[4 * i];
+            l_r[68 + 272 * i] = f.v[4 * i + 1];
+            l_m[272 * i] = f.v[4 * i + 2];
+            l_t[272 * i] = f.v[4 * i + 3];
         }
-        const int base = (lane >> 4) * 256 + (lane & 15);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) f.v[c] = lds[fft_pad(base + 16 * c)];
+        for (int c = 0; c < 16; ++c) f.v[c] = l_b[17 * c];
     };
     // pass 2 backwards: inverse 16-point DFT, then the conjugate twiddles (tw = T2 again, read once per pair)
     auto m2i = [&](Fr& f) {
@@ -788,9 +800,9 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
     };
     auto x4 = [&](Fr& f) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) lds[fft_pad(lane + 64 * i)] = f.v[i];
+        for (int i = 0; i < 16; ++i) l_r[68 * i] = f.v[i];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) f.v[c] = lds[fft_pad(16 * lane + c)];
+        for (int c = 0; c < 16; ++c) f.v[c] = l_17[c];
     };
     // pass 1 backwards: v[i] = 1024 z'[lane + 64 i]; window, store (the two frames of a pair separately: sharing the
     // window read between them bunches their stores and measured slower, 7.45 against 7.34 ms)
@@ -809,6 +821,19 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
         }
     };
 
+    // SOUT: the run's record, written through a buffer resource: a store that may go to the record or to LDS depending
+    // on the sample becomes a FLAT store on a selected pointer otherwise (measured: the pass below 3x slower)
+    const __amdgpu_buffer_rsrc_t rec_rs = __builtin_amdgcn_make_buffer_rsrc(
+        frames_out + (SOUT ? ((long)b * runs_per_utt + ru) * RS : 0), 0, SOUT ? RS * 4 : 0, 0x00020000);
+    auto rec_store2 = [&](int fo, float2 val) {           // record[fo], record[fo + 1]
+        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(u2v{__builtin_bit_cast(unsigned, val.x), __builtin_bit_cast(unsigned, val.y)},
+                                              rec_rs, 4u * (unsigned)fo, 0, 0);
+    };
+    auto rec_store4 = [&](int fo, f4v val) {
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, val), rec_rs, 4u * (unsigned)fo, 0, 0);
+    };
     // SOUT: where the sum of sample s (run coordinates, s >= HEAD) is built up
     auto dest = [&](int s) {
         return (unsigned)(s - 2 * GL_WAVES * HOP) < (unsigned)HEAD ? side_s + (s - 2 * GL_WAVES * HOP) : yseg + s;
@@ -827,9 +852,8 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
         int lane = lane_;
         asm volatile("" : "+v"(lane));
         float* pv = reinterpret_cast<float*>(lds) + slot * HEAD;
-        float* rec = frames_out + ((long)b * runs_per_utt + ru) * RS;
         if (mayhead && fidx < 3) {
-            float* hraw = rec + (fidx == 0 ? 0 : (fidx == 1 ? HOFF1 : HOFF2));
+            const int hraw = fidx == 0 ? 0 : (fidx == 1 ? HOFF1 : HOFF2);
             const int th = HEAD - HOP * fidx;
 #pragma unroll
             for (int i = 0; i < 10; ++i) {
@@ -837,7 +861,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
                 if (i < 9 || c < HALF) {
                     const float2 wv = *reinterpret_cast<const float2*>(win_s + o);
                     const float2 val = make_float2(f.v[i].x * sc * wv.x, f.v[i].y * sc * wv.y);
-                    if (o < th) *reinterpret_cast<float2*>(hraw + o) = val;
+                    if (o < th) rec_store2(hraw + o, val);
                     else if (o < HEAD) *reinterpret_cast<float2*>(pv + o) = val;
                     else *reinterpret_cast<float2*>(dest(HOP * fidx + o)) = val;
                 }
@@ -862,58 +886,41 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
     // samples the next round adds to go back to LDS.
     auto pass = [&](int rd) {
         const int F0 = 2 * GL_WAVES * rd, F1 = min(F0 + 2 * GL_WAVES, nfr);
-        const int lo = rd ? HOP * F0 : HEAD, hi = HOP * F1 + HEAD;
-        float* rec = frames_out + ((long)b * runs_per_utt + ru) * RS;
+        const int qlo = rd ? F0 : HEAD / HOP, qhi = F1 + HEAD / HOP;      // the pass covers hops qlo .. qhi - 1
+        const int npos = (qhi - qlo) * (HOP / 4);                          // ... in groups of four samples
         const float* pbase = reinterpret_cast<const float*>(fft_s);
-        // a wave takes whole hops of samples (wave, wave + 4, ...): which frames contribute, whether the sums are
-        // complete and where everything lies is then the same for all its lanes (scalar arithmetic and branches), and
-        // a lane is left with one address offset: 75 groups of four samples per hop = the 64 lanes + a trip of 11
         int lane = lane_;
         asm volatile("" : "+v"(lane));
-        // (all reads of the wave's hops are issued before the first sum: beside a transforming neighbour an LDS round
-        // trip takes the better part of a microsecond; an absent contribution reads the sample's own place instead)
-        constexpr int NSEG = (2 * GL_WAVES * HOP + HEAD) / HOP, NS = (NSEG + GL_WAVES - 1) / GL_WAVES;
-        constexpr int NT = (HOP / 4 + 63) / 64;
-        f4v a[NS][NT], c[NS][NT][3];
+        // every read of a thread is issued before its first sum (beside a transforming neighbour an LDS round trip
+        // takes the better part of a microsecond); a contribution the round does not have reads a zero instead, so
+        // the sums need no conditions (x + 0 = x). A pass is about 250 instructions a wave: with one or two waves
+        // on a SIMD an instruction issues every four to five cycles, and that, not the data, is what it costs.
+        constexpr int NP = ((2 * GL_WAVES + HEAD / HOP) * (HOP / 4) + GL_THREADS - 1) / GL_THREADS;
+        f4v a[NP], c[NP][3];
+        int sidx[NP];
+        bool fin[NP];
 #pragma unroll
-        for (int g = 0; g < NS; ++g) {
-            const int s0 = min(lo + HOP * (wave + GL_WAVES * g), hi - HOP);
-            const int q = s0 / HOP;
-            const float* dp = dest(s0);
+        for (int u = 0; u < NP; ++u) {
+            const int p = min(lane + 64 * wave + GL_THREADS * u, npos - 1);
+            const int h = p / (HOP / 4), q = qlo + h;
+            const int off = 4 * (p - h * (HOP / 4));
+            sidx[u] = HOP * q + off;
+            fin[u] = q < F1 || F1 == nfr;
+            a[u] = *reinterpret_cast<const f4v*>(dest(sidx[u]));
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const int fq = q - 2 + d;
-                const bool ok = fq >= F0 && fq < F1;
-                const float* cp = ok ? pbase + (fq & 3) * (2 * GL2_LDS) + ((fq >> 2) & 1) * HEAD + (s0 - HOP * fq) : dp;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int off = min(4 * (lane + 64 * t), HOP - 4);
-                    c[g][t][d] = *reinterpret_cast<const f4v*>(cp + off);
-                }
+                const int fq = q - 2 + d;                                   // (sample HOP q of the run = sample
+                const bool ok = fq >= F0 && fq < F1;                        // HOP (2 - d) of frame fq)
+                const float* cp = pbase + (fq & 3) * (2 * GL2_LDS) + ((fq >> 2) & 1) * HEAD + HOP * (2 - d) + off;
+                c[u][d] = *reinterpret_cast<const f4v*>(ok ? cp : zero_s);
             }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) a[g][t] = *reinterpret_cast<const f4v*>(dp + min(4 * (lane + 64 * t), HOP - 4));
         }
 #pragma unroll
-        for (int g = 0; g < NS; ++g) {
-            const int s0 = lo + HOP * (wave + GL_WAVES * g);
-            if (s0 < hi) {
-                const int q = s0 / HOP;
-                const bool fin = q < F1 || F1 == nfr;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int off = 4 * (lane + 64 * t);
-                    f4v acc = a[g][t];
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        const int fq = q - 2 + d;
-                        if (fq >= F0 && fq < F1) acc += c[g][t][d];
-                    }
-                    if (off < HOP) {
-                        if (fin) *reinterpret_cast<f4v*>(rec + HEAD + s0 + off) = acc;
-                        else *reinterpret_cast<f4v*>(dest(s0) + off) = acc;
-                    }
-                }
+        for (int u = 0; u < NP; ++u) {
+            if (lane + 64 * wave + GL_THREADS * u < npos) {
+                const f4v acc = ((a[u] + c[u][0]) + c[u][1]) + c[u][2];
+                if (fin[u]) rec_store4(HEAD + sidx[u], acc);
+                else *reinterpret_cast<f4v*>(dest(sidx[u])) = acc;
             }
         }
     };
@@ -1081,7 +1088,7 @@ void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, f
         const int sout = state && gl2_records_ok(T, run, (long)B * runs_per_utt) ? 1 : 0;
         const size_t lds = (size_t)(((run - 1) * p.hop + p.win + 3) & ~3) * 4 + (size_t)p.win * 4 +
                            (size_t)(FFT_TW + FFT_N / 2 + GL_WAVES * GL2_LDS) * sizeof(cplx) +
-                           (sout ? (size_t)(p.win - p.hop) * 4 : 0);
+                           (sout ? (size_t)(p.win - p.hop) * 4 + 16 : 0);
         auto* kern = sin ? gl_iter2_kernel<1200, 300, true, true>
                          : (sout ? gl_iter2_kernel<1200, 300, false, true> : gl_iter2_kernel<1200, 300, false, false>);
         // (records in -> records out always: eligibility depends on T and the run only, which a chain does not change)

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 o=tacotron_amd/csrc/build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" \
-    -c tacotron_amd/csrc/griffinlim.hip -o $o/griffinlim_$name.o
+    -c tacotron_amd/csrc/${GLSRC:-griffinlim.hip} -o $o/griffinlim_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tacotron_amd/libtaco_v_$name.so \
     $o/api.o $o/gemm.o $o/rnn.o $o/decoder.o $o/dec_persistent.o $o/griffinlim_$name.o
 echo tacotron_amd/libtaco_v_$name.so

@@ -22,5 +22,7 @@ for rep in range(3):
     idx += [14, 15, 16, 17, 18, 19, 20, 21]
     names += ['r1.B2', 'r1.pass', 'r1.B3', 'r2.B2', 'r2.pass', 'r2.end']
     idx += [24, 25, 26, 27, 28, 29]
+    if os.environ.get('GL_STAMPS_PASS'):
+        names += ['r1.issued', 'r1.landed', 'r2.issued', 'r2.landed']; idx += [30, 31, 32, 33]
     names = [n for n in names if n]
     print(' '.join('%s %d' % (n, t[i] - t[0]) for n, i in zip(names, idx)), flush=True)
