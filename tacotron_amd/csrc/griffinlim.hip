@@ -642,11 +642,12 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
     // Table values (twiddles) of the next stage are read into tw[] for both frames of a pair at once, at a point where
     // the only LDS reads in flight are older ones: LDS returns in order, so a table read issued behind the other
     // frame's exchange could only be used after that exchange had landed, which is the wait the pairing is there to hide.
-    cplx tw[15];
-    auto ld_T2 = [&]() {
+    cplx tw[12], tw2[15];
+    // (the pass-2 twiddles depend on lane & 15 only: read once, they stay in registers now that the exchange addresses
+    // no longer take forty of them)
 #pragma unroll
-        for (int i = 0; i < 15; ++i) tw[i] = T2[i * 16 + (lane & 15)];
-    };
+    for (int i = 0; i < 15; ++i) tw2[i] = T2[i * 16 + (lane & 15)];
+    auto ld_T2 = [&]() {};
     auto ld_T3 = [&]() {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -705,10 +706,10 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
     };
     auto m2f = [&](Fr& f) {
         cplx (&v)[16] = f.v;
-        cmul_v4(v[1], v[2], v[3], v[4], tw[0], tw[1], tw[2], tw[3]);
-        cmul_v4(v[5], v[6], v[7], v[8], tw[4], tw[5], tw[6], tw[7]);
-        cmul_v4(v[9], v[10], v[11], v[12], tw[8], tw[9], tw[10], tw[11]);
-        cmul_v3(v[13], v[14], v[15], tw[12], tw[13], tw[14]);
+        cmul_v4(v[1], v[2], v[3], v[4], tw2[0], tw2[1], tw2[2], tw2[3]);
+        cmul_v4(v[5], v[6], v[7], v[8], tw2[4], tw2[5], tw2[6], tw2[7]);
+        cmul_v4(v[9], v[10], v[11], v[12], tw2[8], tw2[9], tw2[10], tw2[11]);
+        cmul_v3(v[13], v[14], v[15], tw2[12], tw2[13], tw2[14]);
     };
     // Radix-4 pass (tw = T3 of the lane's butterflies) -> v[s + 4 i'] = Z[t_s + 256 i']; bin pairs in registers
     // (0,15) (4,11) (3,12) (7,8) (1,14) (5,10) (2,13) (6,9) = pair_bin order; split -> re-phase against the target
@@ -793,10 +794,10 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
     auto m2i = [&](Fr& f) {
         dft16<true>(f.v);
         cplx (&v)[16] = f.v;
-        cmul_vc4(v[1], v[2], v[3], v[4], tw[0], tw[1], tw[2], tw[3]);
-        cmul_vc4(v[5], v[6], v[7], v[8], tw[4], tw[5], tw[6], tw[7]);
-        cmul_vc4(v[9], v[10], v[11], v[12], tw[8], tw[9], tw[10], tw[11]);
-        cmul_vc3(v[13], v[14], v[15], tw[12], tw[13], tw[14]);
+        cmul_vc4(v[1], v[2], v[3], v[4], tw2[0], tw2[1], tw2[2], tw2[3]);
+        cmul_vc4(v[5], v[6], v[7], v[8], tw2[4], tw2[5], tw2[6], tw2[7]);
+        cmul_vc4(v[9], v[10], v[11], v[12], tw2[8], tw2[9], tw2[10], tw2[11]);
+        cmul_vc3(v[13], v[14], v[15], tw2[12], tw2[13], tw2[14]);
     };
     auto x4 = [&](Fr& f) {
 #pragma unroll
