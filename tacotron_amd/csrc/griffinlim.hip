@@ -648,6 +648,13 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
 #pragma unroll
     for (int i = 0; i < 15; ++i) tw2[i] = T2[i * 16 + (lane & 15)];
     auto ld_T2 = [&]() {};
+    // ... and so do the lane's twenty window values (analysis and synthesis use the same ones)
+    float2 wreg[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const int c = lane + 64 * i;
+        wreg[i] = *reinterpret_cast<const float2*>(win_s + 2 * ((i < 9 || c < HALF) ? c : 0));
+    }
     auto ld_T3 = [&]() {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -661,7 +668,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
         for (int i = 0; i < 10; ++i) {
             const int c = lane + 64 * i;
             const int cc = (i < 9 || c < HALF) ? c : 0;
-            const float2 wv = *reinterpret_cast<const float2*>(win_s + 2 * cc);
+            const float2 wv = wreg[i];
             const float2 sf = *reinterpret_cast<const float2*>(f.ys + 2 * cc);
             const float2 sg = *reinterpret_cast<const float2*>(g.ys + 2 * cc);
             cplx zf = {sf.x * wv.x, sf.y * wv.y}, zg = {sg.x * wv.x, sg.y * wv.y};
@@ -815,7 +822,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
             for (int i = 0; i < 10; ++i) {
                 const int c = lane + 64 * i;
                 if (i < 9 || c < HALF) {
-                    const float2 wv = *reinterpret_cast<const float2*>(win_s + 2 * c);
+                    const float2 wv = wreg[i];
                     *reinterpret_cast<float2*>(f.out + 2 * c) = make_float2(f.v[i].x * sc * wv.x, f.v[i].y * sc * wv.y);
                 }
             }
@@ -860,7 +867,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
             for (int i = 0; i < 10; ++i) {
                 const int c = lane + 64 * i, o = 2 * c;
                 if (i < 9 || c < HALF) {
-                    const float2 wv = *reinterpret_cast<const float2*>(win_s + o);
+                    const float2 wv = wreg[i];
                     const float2 val = make_float2(f.v[i].x * sc * wv.x, f.v[i].y * sc * wv.y);
                     if (o < th) rec_store2(hraw + o, val);
                     else if (o < HEAD) *reinterpret_cast<float2*>(pv + o) = val;
@@ -872,7 +879,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
             for (int i = 0; i < 10; ++i) {
                 const int c = lane + 64 * i, o = 2 * c;
                 if (i < 9 || c < HALF) {
-                    const float2 wv = *reinterpret_cast<const float2*>(win_s + o);
+                    const float2 wv = wreg[i];
                     const float2 val = make_float2(f.v[i].x * sc * wv.x, f.v[i].y * sc * wv.y);
                     if (128 * i + 126 < HEAD) *reinterpret_cast<float2*>(pv + o) = val;
                     else if (128 * i >= HEAD) *reinterpret_cast<float2*>(dest(HOP * fidx + o)) = val;
