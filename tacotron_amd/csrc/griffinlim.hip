@@ -655,12 +655,12 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
         const int c = lane + 64 * i;
         wreg[i] = *reinterpret_cast<const float2*>(win_s + 2 * ((i < 9 || c < HALF) ? c : 0));
     }
-    auto ld_T3 = [&]() {
+    // ... and the radix-4 pass's twiddles of the lane's four butterflies
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) tw[3 * q + i] = T3[i * 256 + lane + 64 * q];
-    };
+        for (int i = 0; i < 3; ++i) tw[3 * q + i] = T3[i * 256 + lane + 64 * q];
+    auto ld_T3 = [&]() {};
     auto a1 = [&](Fr& f, Fr& g) {
         // analysis window, even/odd packing z[c] = (y[2c], y[2c+1]), c = lane + 64 i: i <= 8 always inside the window,
         // i = 9 for the first HALF - 576 lanes, i >= 10 never; both frames of the pair with one read of the window
