@@ -1065,6 +1065,10 @@ constexpr long GL2_RECORDS_MIN_GRID = 257;
 static bool gl2_records_ok(int T, int run, long grid) {
     const int last = T % run;
     if (!(last == 0 || last >= 3)) return false;
+    // the records of an utterance must fit where its frames would lie (the caller's buffers are sized for frames):
+    // true from T = 4 (runs of 8) / T = 6 (runs of 16) on
+    const long runs_per_utt = (T + run - 1) / run;
+    if (runs_per_utt * (2 * (1200 - 300) + 300 * run) > (long)T * 1200) return false;
     if (const char* e = getenv("TACO_GL_FRAME_STATE")) return atoi(e) == 0;
     return grid >= GL2_RECORDS_MIN_GRID;
 }

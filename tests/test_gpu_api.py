@@ -215,13 +215,15 @@ def test_griffin_lim_row_slice_input(engine, hp):
     assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize('B,T,iters', [(1, 3, 3), (1, 16, 2), (2, 19, 3), (1, 17, 3), (2, 18, 2), (3, 40, 4), (1, 8, 1),
-                                       (4, 27, 3), (5, 200, 4), (33, 100, 3), (2, 1000, 5)])
+@pytest.mark.parametrize('B,T,iters', [(1, 3, 3), (4, 3, 2), (6, 4, 2), (5, 5, 2), (3, 6, 2), (1, 16, 2), (2, 19, 3),
+                                       (1, 17, 3), (2, 18, 2), (3, 40, 4), (1, 8, 1), (4, 27, 3), (5, 200, 4),
+                                       (33, 100, 3), (2, 1000, 5)])
 def test_griffin_lim_run_records_match_frame_state(engine, hp, monkeypatch, B, T, iters):
     """Between iterations the vocoder keeps the overlap-added signal as run records (the sums of a run of frames plus
     the raw head frames its neighbours need) instead of the windowed frames; the additions per sample and their order
     are the same, so the waveform must equal the frame-state result bit for bit: runs of 8 and of 16 frames, whole and
-    short last runs, utterances of a single run, last runs of one or two frames (which keep the frame state)."""
+    short last runs, utterances of a single run, last runs of one or two frames and utterances whose records would not
+    fit the frame buffers (which keep the frame state)."""
     rng = np.random.default_rng(1000 * B + T)
     lin = rng.random((B, T, hp.num_freq)).astype(np.float32)
     monkeypatch.setenv('TACO_GL_FRAME_STATE', '1')
