@@ -32,6 +32,22 @@ namespace taco {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef PD_AUX_LD        // cache policy of the hand-off granules (experiments): 16 = sc1, 1 = sc0, 17 = both, 0 = none
+#define PD_AUX_LD 16
+#endif
+#ifndef PD_AUX_ST
+#define PD_AUX_ST 16
+#endif
+#ifdef PD_INV_L1         // (experiment) polls = invalidate the CU's vector L1, then plain loads: L2 hits within an XCD
+#ifndef PD_INV_SCOPE
+#define PD_INV_SCOPE sc0
+#endif
+#define PD_STR2(x) #x
+#define PD_STR(x) PD_STR2(x)
+#define PD_POLL_INV() asm volatile("buffer_inv " PD_STR(PD_INV_SCOPE) ::: "memory")
+#else
+#define PD_POLL_INV() do {} while (0)
+#endif
 constexpr int PD_THREADS = 256;   // one wave per SIMD: each wave may use the whole 512-entry register file
 constexpr int PD_WAVES = 4;
 constexpr unsigned long long PD_WAIT_LIMIT_TICKS = 1000000000ull;   // 10 s of s_memrealtime (100 MHz) per wait
@@ -53,16 +69,16 @@ enum { ST_PRE1 = 0, ST_PRE2, ST_ATTG, ST_ATTC, ST_QUERY, ST_PROJ, ST_G1G, ST_G1C
 struct GQuad { u32x4 lo, hi; };
 __device__ __forceinline__ GQuad pd_ldg(__amdgpu_buffer_rsrc_t rs, unsigned float_off) {
     GQuad g;
-    g.lo = __builtin_amdgcn_raw_buffer_load_b128(rs, float_off * 4u, 0, 16 /* sc1 */);
-    g.hi = __builtin_amdgcn_raw_buffer_load_b128(rs, float_off * 4u + 16u, 0, 16);
+    g.lo = __builtin_amdgcn_raw_buffer_load_b128(rs, float_off * 4u, 0, PD_AUX_LD /* sc1 */);
+    g.hi = __builtin_amdgcn_raw_buffer_load_b128(rs, float_off * 4u + 16u, 0, PD_AUX_LD);
     return g;
 }
 // same with the address split into a per-lane byte offset (one VGPR for the whole kernel) and a wave-uniform
 // byte offset (SGPR): the K loop of a stage then needs no address registers at all
 __device__ __forceinline__ GQuad pd_ldg2(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned uni_bytes) {
     GQuad g;
-    g.lo = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_bytes, uni_bytes, 16 /* sc1 */);
-    g.hi = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_bytes + 16u, uni_bytes, 16);
+    g.lo = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_bytes, uni_bytes, PD_AUX_LD /* sc1 */);
+    g.hi = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_bytes + 16u, uni_bytes, PD_AUX_LD);
     return g;
 }
 __device__ __forceinline__ bool gq_ok(const GQuad& g, unsigned tag) {
@@ -81,8 +97,8 @@ __device__ __forceinline__ void pd_stg(__amdgpu_buffer_rsrc_t rs, unsigned float
     const float a = v.x, b = v.y, c = v.z, d = v.w;
     const u32x4 lo = {__float_as_uint(a), tag, __float_as_uint(b), tag};
     const u32x4 hi = {__float_as_uint(c), tag, __float_as_uint(d), tag};
-    __builtin_amdgcn_raw_buffer_store_b128(lo, rs, float_off * 4u, 0, 16 /* sc1 */);
-    __builtin_amdgcn_raw_buffer_store_b128(hi, rs, float_off * 4u + 16u, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(lo, rs, float_off * 4u, 0, PD_AUX_ST /* sc1 */);
+    __builtin_amdgcn_raw_buffer_store_b128(hi, rs, float_off * 4u + 16u, 0, PD_AUX_ST);
 }
 
 // Bounded wait bookkeeping: a wave whose single wait has lasted PD_WAIT_LIMIT_TICKS of the 100 MHz real-time clock
@@ -161,6 +177,7 @@ __device__ __forceinline__ f32x4 pd_mma(const float4 (&w)[CH], __amdgpu_buffer_r
         for (int i = 0; i < (NX > 0 ? NX : 1); ++i) havex[i] = false;
         while (true) {
             bool ok = true;
+            PD_POLL_INV();
 #pragma unroll
             for (int i = 0; i < PD_BATCH; ++i) {
                 const int ks = (h + i) * PD_WAVES + wave;
@@ -239,6 +256,7 @@ __device__ __forceinline__ f32x4 pd_wait_quad(__amdgpu_buffer_rsrc_t rs, unsigne
     GQuad g;
     spin.begin(tag);
     while (true) {
+        PD_POLL_INV();
         g = pd_ldg(rs, float_off);
         if (__all(gq_ok(g, tag)) || spin.give_up()) break;
     }
@@ -600,7 +618,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
             // publish this half's scores as {e, tag} granules (one coalesced store), fetch the other half's
             for (int t = tid; t < t_n; t += PD_THREADS)
                 __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(e_s[t_lo + t]), T + 6u}, rs,
-                                                      (a.o_e + (unsigned)(b_att * a.T_in + t_lo + t) * 2u) * 4u, 0, 16);
+                                                      (a.o_e + (unsigned)(b_att * a.T_in + t_lo + t) * 2u) * 4u, 0, PD_AUX_ST);
             PD_STAMP();
             {
                 const int o_n = a.T_in - t_n;                      // the rows of the other parts: [0, t_lo), [t_lo + t_n, T_in)
@@ -610,8 +628,9 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
                     u32x2 g = {0u, T + 6u};
                     spin.begin(T + 6u);
                     while (true) {
+                        PD_POLL_INV();
                         if (ti < o_n)
-                            g = __builtin_amdgcn_raw_buffer_load_b64(rs, (a.o_e + (unsigned)(b_att * a.T_in + t) * 2u) * 4u, 0, 16);
+                            g = __builtin_amdgcn_raw_buffer_load_b64(rs, (a.o_e + (unsigned)(b_att * a.T_in + t) * 2u) * 4u, 0, PD_AUX_LD);
                         if (__all(g.y == T + 6u) || spin.give_up()) break;
                     }
                     if (ti < o_n) e_s[t] = __uint_as_float(g.x);
