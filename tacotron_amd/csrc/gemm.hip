@@ -34,13 +34,16 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // POOL: the A operand is max(x[t], x[t+1]) (the max-pool folded into proj_1's loader); a template parameter so that the
 // k loop is one basic block, whose address arithmetic and loads the scheduler can spread between the MFMAs
-template <int BM, int BN, bool POOL>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
+// NW: waves per workgroup, 4 (2 x 2 over the tile) or 8 (2 x 4: a wave owns BM/2 x BN/4)
+template <int BM, int BN, bool POOL, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void conv_gemm_kernel(GemmArgs a) {
     constexpr int BK = 16, PAD = 4, AST = BK + 4;   // A row stride 20: the 16 lanes of a ds_read_b128 group hit 16 bank quads
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int NTH = 64 * NW, WCOLS = NW / 2;
+    constexpr int WM = BM / 2, WN = BN / WCOLS;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int NA = BM * 4 / 256;          // float4 A loads per thread per tile
-    constexpr int NB = BK * BN / 4 / 256;     // float4 B loads per thread per tile
+    constexpr int NA = BM * 4 / NTH;          // float4 A loads per thread per tile
+    constexpr int NB = BK * BN / 4 / NTH;     // float4 B loads per thread per tile
+    static_assert(NA >= 1 && NB >= 1 && TM >= 1 && TN >= 1, "tile too small for this many waves");
     __shared__ __attribute__((aligned(16))) float As[2][BM][AST];     // row-major: stashed as it is loaded (16 bytes along k)
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PAD];
 
@@ -59,8 +62,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
         m0 = (yy * 8 + xcd) * BM;
         if (m0 >= a.M) return;                    // (grid rounded up to whole rounds of 8 row blocks)
     }
-    const int wm = (wave >> 1) * WM;
-    const int wn = (wave & 1) * WN;
+    const int wm = (wave / WCOLS) * WM;
+    const int wn = (wave % WCOLS) * WN;
 
     // a grouped launch runs several convolutions over the same input (the CBHG conv bank) as grid.z slices
     const float* W = a.W;
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     int at[NA];              // t within the sequence, or a value that fails every range test for rows past M
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int f = tid + 256 * i;
+        const int f = tid + NTH * i;
         const int row = f >> 2, kq = f & 3;
         const int m = m0 + row;
         const int t = m % a.T;
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     const float* wp[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int f = tid + 256 * i;
+        const int f = tid + NTH * i;
         const int k = f / (BN / 4), nq = f % (BN / 4);
         wp[i] = W + (size_t)k * a.ldw + n0 + 4 * nq;
     }
@@ -137,14 +140,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
 #define CG_STASH(buf)                                                                                    \
     do {                                                                                                 \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                 \
-            const int f = tid + 256 * i;                                                                 \
+            const int f = tid + NTH * i;                                                                 \
             const int row = f >> 2, k = 4 * (f & 3);                                                     \
             f32x4v v = ra[i];                                                                            \
             if (POOL) v = __builtin_elementwise_max(v, rp[i]);                                           \
             *reinterpret_cast<f32x4v*>(&As[buf][row][k]) = v;                                            \
         }                                                                                                \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                 \
-            const int f = tid + 256 * i;                                                                 \
+            const int f = tid + NTH * i;                                                                 \
             const int k = f / (BN / 4), nq = f % (BN / 4);                                               \
             *reinterpret_cast<f32x4v*>(&Bs[buf][k][4 * nq]) = rb[i];                                     \
         }                                                                                                \
@@ -332,6 +335,9 @@ void launch_conv_gemm(const GemmArgs& a_in, hipStream_t s, Timing* tm) {
         // the k order of an element's sum is the same for every tile shape, so the choice does not change a bit
         if (a.pool) hipLaunchKernelGGL((conv_gemm_kernel<128, 64, true>), cg_grid(a, 128, 64, z), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv_gemm_kernel<128, 64, false>), cg_grid(a, 128, 64, z), dim3(256), 0, s, a);
+    } else if (big && getenv("TACO_GEMM_W8")) {     // (experiment) eight waves per 128 x 128 tile
+        if (a.pool) hipLaunchKernelGGL((conv_gemm_kernel<128, 128, true, 8>), cg_grid(a, 128, 128, z), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<128, 128, false, 8>), cg_grid(a, 128, 128, z), dim3(512), 0, s, a);
     } else if (big) {
         if (a.pool) hipLaunchKernelGGL((conv_gemm_kernel<128, 128, true>), cg_grid(a, 128, 128, z), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv_gemm_kernel<128, 128, false>), cg_grid(a, 128, 128, z), dim3(256), 0, s, a);
