@@ -48,6 +48,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #else
 #define PD_POLL_INV() do {} while (0)
 #endif
+#ifndef PD_SLEEP         // s_sleep argument after a failed poll (64 clocks each)
+#define PD_SLEEP 1
+#endif
 constexpr int PD_THREADS = 256;   // one wave per SIMD: each wave may use the whole 512-entry register file
 constexpr int PD_WAVES = 4;
 constexpr unsigned long long PD_WAIT_LIMIT_TICKS = 1000000000ull;   // 10 s of s_memrealtime (100 MHz) per wait
@@ -138,7 +141,7 @@ struct Spin {
                 dead = true;
             }
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(PD_SLEEP);
         return dead;
     }
 };
