@@ -260,7 +260,10 @@ def main():
         barrier()
         # decodes side by side: as many as fit the chip for mel + linear; one at a time when the vocoder's full-chip
         # launches of the other batches in flight run beside them (include/taco.h, taco_set_persist_budget)
-        eng.set_persist_budget(32 * ((B + 15) // 16) if to_wav else 0)
+        budget = 32 * ((B + 15) // 16) if to_wav else 0
+        if os.environ.get('TACO_BENCH_DECODES'):             # (tuning) decodes allowed side by side, 0 = no limit
+            budget = int(os.environ['TACO_BENCH_DECODES']) * 32 * ((B + 15) // 16)
+        eng.set_persist_budget(budget)
         t0 = time.perf_counter()
         for _ in range(n_steps):
             step(to_wav)
