@@ -1086,18 +1086,18 @@ void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, f
     const bool two = dflt && !librosa && !first && run == GL_RUN && p.lds_image && !getenv("TACO_GL_ONE_FRAME");
     // small jobs: shorter runs (down to one frame, or one pair of frames, per wave) until the grid covers the chip
     // twice; the overlap-add order per sample does not depend on the run length, so results are bit-identical
+    const int sin = state ? *state : 0;                  // what frames_in holds: 0 = frames, else run records of that run length
     if (two) {
-        run = gl2_run(B, T);
+        run = sin ? sin : gl2_run(B, T);
     } else {
         while (run > GL_WAVES && (long)B * ((T + run - 1) / run) < 512) run -= GL_WAVES;
     }
     const int runs_per_utt = (T + run - 1) / run;
     gl_prepare_device();
     const dim3 grid((unsigned)(B * runs_per_utt));
-    const int sin = state ? *state : 0;                  // what frames_in holds: 0 = frames, 1 = run records
     if (two) {
         // the state written: run records when the caller can take them (it passes `state`) and the geometry allows
-        const int sout = state && gl2_records_ok(T, run, (long)B * runs_per_utt) ? 1 : 0;
+        const int sout = sin || (state && gl2_records_ok(T, run, (long)B * runs_per_utt)) ? 1 : 0;
         const size_t lds = (size_t)(((run - 1) * p.hop + p.win + 3) & ~3) * 4 + (size_t)p.win * 4 +
                            (size_t)(FFT_TW + FFT_N / 2 + GL_WAVES * GL2_LDS) * sizeof(cplx) +
                            (sout ? (size_t)(p.win - p.hop) * 4 + 16 : 0);
@@ -1106,7 +1106,7 @@ void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, f
         // (records in -> records out always: eligibility depends on T and the run only, which a chain does not change)
         hipLaunchKernelGGL(kern, grid, dim3(GL_THREADS), lds, s, frames_in, mag, frames_out, p.lds_image, B, T,
                            p.nbins, run, runs_per_utt);
-        if (state) *state = sin ? 1 : sout;
+        if (state) *state = sout ? run : 0;
     } else {
         if (sin) {                                       // cannot happen within a chain (same B, T, flavour throughout)
             fprintf(stderr, "taco: launch_gl_iter: run records handed to a kernel that reads frames\n");
@@ -1324,7 +1324,7 @@ void launch_gl_ola(const GLPlan& p, const float* frames, float* wav, int B, int 
                    int state) {
     if (tm) tm->begin(KK_GL_OLA, s);
     if (state) {                                       // run records (default geometry only, see launch_gl_iter)
-        const int run = gl2_run(B, T);
+        const int run = state;
         const int runs_per_utt = (T + run - 1) / run;
         const long L4 = (long)B * ((long)(T - 1) * p.hop + p.win) / 4;
         const int blocks = (int)std::max<long>(1, std::min<long>(4096, (L4 + 255) / 256));

@@ -174,8 +174,8 @@ void launch_gl_mag(const float* lin, float* mag, size_t n, float min_db, float r
 // loop (normalised, trimmed, reflect-padded signal between iterations; first synthesis from the phases
 // exp(2 pi i phase_u), phase_u [B*T][nbins] or null = zero phase).
 // state: null = the loop's state is the frames, in and out. Otherwise *state says what frames_in holds (0 = frames,
-// 1 = run records, the overlap-added signal per run of frames as gl_iter2_kernel lays it out, which fits the same
-// buffer) and receives what frames_out holds after the launch; hand it from launch to launch and to launch_gl_ola.
+// 8 / 16 = run records of that many frames, the overlap-added signal as gl_iter2_kernel lays it out, which fits the
+// same buffer) and receives what frames_out holds after the launch; hand it from launch to launch and to launch_gl_ola.
 // All launches of a chain must be given the same B and T.
 void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, float* frames_out, int B, int T,
                     int first, hipStream_t s, Timing* tm, bool librosa = false, const float* phase_u = nullptr,
