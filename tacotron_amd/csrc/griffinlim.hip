@@ -639,15 +639,14 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
         f.ys = yseg + HOP * fi;
         f.out = frames_out + (fb + m0 + fi) * WIN;
     };
-    // Table values (twiddles) of the next stage are read into tw[] for both frames of a pair at once, at a point where
-    // the only LDS reads in flight are older ones: LDS returns in order, so a table read issued behind the other
-    // frame's exchange could only be used after that exchange had landed, which is the wait the pairing is there to hide.
+    // Table values: the pass-2 twiddles (they depend on lane & 15 only), the radix-4 pass's twiddles of the lane's four
+    // butterflies and the lane's twenty window values are read once per workgroup and stay in registers (room for them
+    // since the exchange addresses no longer take forty); only the split twiddles are read from LDS at each use.
+    // (Before, tables were read per pair of frames, ahead of the other frame's exchange: LDS returns in order, so a
+    // table read issued behind an exchange could only be used after that exchange had landed.)
     cplx tw[12], tw2[15];
-    // (the pass-2 twiddles depend on lane & 15 only: read once, they stay in registers now that the exchange addresses
-    // no longer take forty of them)
 #pragma unroll
     for (int i = 0; i < 15; ++i) tw2[i] = T2[i * 16 + (lane & 15)];
-    auto ld_T2 = [&]() {};
     // ... and so do the lane's twenty window values (analysis and synthesis use the same ones)
     float2 wreg[10];
 #pragma unroll
@@ -660,10 +659,9 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int i = 0; i < 3; ++i) tw[3 * q + i] = T3[i * 256 + lane + 64 * q];
-    auto ld_T3 = [&]() {};
     auto a1 = [&](Fr& f, Fr& g) {
         // analysis window, even/odd packing z[c] = (y[2c], y[2c+1]), c = lane + 64 i: i <= 8 always inside the window,
-        // i = 9 for the first HALF - 576 lanes, i >= 10 never; both frames of the pair with one read of the window
+        // i = 9 for the first HALF - 576 lanes, i >= 10 never
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
             const int c = lane + 64 * i;
@@ -950,17 +948,17 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
             GL_STAMP(sb);
             a1(A, Bf);
             if constexpr (SOUT) gl_lds_barrier();           // (B1) every input of the round is in registers
-            d1(A);   x_pass1(A);  ld_T2();
+            d1(A);   x_pass1(A);
             d1(Bf);  GL2_LAND(A.v);  x_pass1(Bf);
             GL_STAMP(sb + 1);
             m2f(A);  dft16<false>(A.v);  GL2_LAND(Bf.v); x_pass2(A);
-            m2f(Bf); ld_T3(); dft16<false>(Bf.v); GL2_LAND(A.v);  x_pass2(Bf);
+            m2f(Bf); dft16<false>(Bf.v); GL2_LAND(A.v);  x_pass2(Bf);
             GL_STAMP(sb + 2);
             const int fn = fi + 2 * GL_WAVES;               // the wave's next pair
             m3(A, mkA, mnA, m512A);   GL2_LAND(Bf.v); x3(A);
             if (fn < nfr) load_mag(mkA, mnA, m512A, fn);
             GL_STAMP(sb + 3);
-            m3(Bf, mkB, mnB, m512B);  ld_T2();  GL2_LAND(A.v);  x3(Bf);
+            m3(Bf, mkB, mnB, m512B);  GL2_LAND(A.v);  x3(Bf);
             if (fn < nfr) load_mag(mkB, mnB, m512B, min(fn + GL_WAVES, nfr - 1));
             GL_STAMP(sb + 4);
             m2i(A);  GL2_LAND(Bf.v); x4(A);
