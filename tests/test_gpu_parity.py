@@ -66,6 +66,43 @@ def test_conv_gemm_kernel(engine, M, T, Cin, taps, N, act, pool, extras):
     assert max_abs(got, ref) < 1e-4 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize('N,pool', [(256, 1), (128, 0), (1025, 0)])
+def test_conv_gemm_big_tiles(engine, monkeypatch, N, pool):
+    """The large-M tile shapes (128 x 128, 128 x 64; the 64 x 64 kernel takes the shapes of test_conv_gemm_kernel) against
+    fp64 numpy, and bit for bit against each other: 64 x 64 tiles forced through a small sub-problem of the same rows,
+    and the eight-wave layout of the 128 x 128 tile (TACO_GEMM_W8). An element's sum has the same k order in all."""
+    import torch
+    M, T, Cin, taps = 32768, 512, 64, 3          # 256 row blocks of 128: the big-tile rule holds for N = 128 too
+    rng = np.random.default_rng(N + pool)
+    B = M // T
+    x = rng.standard_normal((B, T, Cin)).astype(np.float32)
+    w = (rng.standard_normal((taps, Cin, N)) / np.sqrt(taps * Cin)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    xin = O.maxpool2_same(x.astype(np.float64)) if pool else x.astype(np.float64)
+    ref = np.maximum(O.conv1d_same(xin, w.astype(np.float64), bias.astype(np.float64)), 0)
+    ldw = (N + 127) // 128 * 128
+    wp = np.zeros((taps * Cin, ldw), np.float32)
+    wp[:, :N] = w.reshape(taps * Cin, N)
+    dev = engine.device
+    X, W, Bi = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (x, wp, bias))
+
+    def run(rows):
+        C = torch.zeros(rows, N, dtype=torch.float32, device=dev)
+        rc = engine.lib.taco_debug_conv_gemm(X.data_ptr(), Cin, rows, T, Cin, taps, (taps - 1) // 2, W.data_ptr(), ldw, N,
+                                             Bi.data_ptr(), None, None, None, N, C.data_ptr(), N, 1, pool, None)
+        assert rc == 0, engine.lib.taco_last_error()
+        torch.cuda.synchronize()
+        return _np(C)
+
+    monkeypatch.delenv('TACO_GEMM_W8', raising=False)
+    big = run(M)
+    assert rel_l1(big.reshape(B, T, N), ref) < 2e-6
+    small = run(2 * T)                                   # two utterances: 64 x 64 tiles
+    assert np.array_equal(small, big[:2 * T])
+    monkeypatch.setenv('TACO_GEMM_W8', '1')
+    assert np.array_equal(run(M), big)
+
+
 @pytest.mark.parametrize('B,T_in', [(1, 5), (2, 7), (3, 37), (5, 150)])
 def test_encode(engine, hp, weights, B, T_in):
     rng = np.random.default_rng(10 * B + T_in)
