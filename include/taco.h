@@ -35,8 +35,11 @@ typedef void* taco_stream_t;
 
 /* Shapes of the graph; field-for-field the model/audio/eval values of
  * /root/reference/hparams.py:13-21,25-51,65-67 (hop/win already derived as
- * tools/audio.py:162-163 does). */
+ * tools/audio.py:162-163 does). The first field carries the struct's size (see below). */
 typedef struct TacoHParams {
+    uint32_t struct_size;         /* = sizeof(TacoHParams) of the header the caller was built against; taco_create
+                                     refuses any other value (fields are only ever appended: a caller with an older,
+                                     shorter struct is told so instead of having bytes read past its end) */
     int32_t num_chars;            /* len(text.characters.chars) = 95, data/batch.py:38 */
     int32_t embedded_depth;       /* 256 */
     int32_t prenet_depth1;        /* 256 */

@@ -336,8 +336,10 @@ def find_endpoint(wav, sample_rate=24000, threshold_db=-40, min_silence_sec=0.8)
 
 
 def wav_to_int16(wav):
-    """save_wav's scaling (audio.py:16-17)."""
-    w = np.asarray(wav, np.float64) * (32767 / max(0.01, np.max(np.abs(wav))))
+    """save_wav's scaling (audio.py:16-17), in place on a copy so that it happens in the input's own float type."""
+    w = np.asarray(wav)
+    w = w.astype(w.dtype if w.dtype.kind == 'f' else np.float64, copy=True)
+    w *= 32767 / max(0.01, np.max(np.abs(w)))
     return w.astype(np.int16)
 
 

@@ -19,7 +19,7 @@ _HP_FIELDS = [
 
 
 class TacoHParams(ctypes.Structure):
-    _fields_ = ([(n, ctypes.c_int32) for n in _HP_FIELDS] +
+    _fields_ = ([('struct_size', ctypes.c_uint32)] + [(n, ctypes.c_int32) for n in _HP_FIELDS] +
                 [('min_level_db', ctypes.c_float), ('ref_level_db', ctypes.c_float), ('power', ctypes.c_float),
                  ('max_iters', ctypes.c_int32), ('griffin_lim_iters', ctypes.c_int32),
                  ('encoder_pooling_width', ctypes.c_int32), ('encoder_pooling_stride', ctypes.c_int32),
@@ -110,6 +110,7 @@ def make_hparams_struct(hp):
     from .text.characters import chars
     n_fft, hop, win = hp.stft_params()
     s = TacoHParams()
+    s.struct_size = ctypes.sizeof(TacoHParams)
     s.num_chars = len(chars)
     s.embedded_depth = hp.embedded_depth
     s.prenet_depth1, s.prenet_depth2 = hp.prenet_depths

@@ -563,6 +563,11 @@ extern "C" int taco_create(const TacoHParams* hp, const TacoWeightEntry* weights
                            taco_handle* out) {
     if (!hp || !weights || !out) return fail("taco_create: null argument");
     *out = nullptr;
+    // the first field is the size of the caller's struct: fields are only ever appended, so a mismatch means caller and
+    // library were built against different headers (checked before any other field is read)
+    if (hp->struct_size != sizeof(TacoHParams))
+        return fail("taco_create: TacoHParams.struct_size is %u but this library's struct has %zu bytes "
+                    "(caller built against another include/taco.h?)", hp->struct_size, sizeof(TacoHParams));
     // shapes the kernels are written for
     const TacoHParams& p = *hp;
     auto m16 = [](int v) { return v > 0 && v % 16 == 0; };

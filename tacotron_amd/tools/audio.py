@@ -64,6 +64,33 @@ def _db_to_amp(x):
     return np.power(10.0, x * 0.05)
 
 
+def _amp_to_db(x):
+    """audio.py:212-217."""
+    return 20 * np.log10(np.maximum(1e-5, x))
+
+
+def _normalize(S):
+    """audio.py:254-264."""
+    return np.clip((S - hparams.get('min_level_db')) / -float(hparams.get('min_level_db')), 0, 1)
+
+
+def _normalize_inv(S):
+    """audio.py:266-274."""
+    return (np.clip(S, 0, 1) * -float(hparams.get('min_level_db'))) + hparams.get('min_level_db')
+
+
+def _stft_params():
+    """audio.py:150-164: (n_fft, hop_length, win_length)."""
+    return hparams.stft_params()
+
+
+def pre_emphasis(x, coef=None):
+    """audio.py:91-109: scipy.signal.lfilter([1, -preemphasis], [1], x): y[n] = x[n] - a*x[n-1] (float64)."""
+    from scipy import signal
+    a = float(hparams.get('preemphasis')) if coef is None else float(coef)
+    return signal.lfilter([1, -a], [1], x)
+
+
 def _hz_to_mel(f):
     """librosa.hz_to_mel(htk=False): linear below 1 kHz (200/3 Hz per mel), logarithmic above (Slaney)."""
     f = np.asarray(f, np.float64)
@@ -178,9 +205,15 @@ def find_endpoint(wav, threshold_db=-40, min_silence_sec=0.8):
 
 
 def wav_to_int16(wav):
-    wav = np.asarray(wav, np.float64)
-    peak = np.max(np.abs(wav)) if len(wav) else 0.0
-    return (wav * (32767 / max(0.01, peak))).astype(np.int16)
+    """audio.py:16-17: `wav *= 32767 / max(0.01, max|wav|)` then the int16 cast, in the dtype of the array handed in
+    (the reference scales in place: a float32 waveform is scaled in float32, the float64 output of pre_emphasis_inv in
+    float64 - pinned by tests/golden/host_dsp_goldens.npz). The caller's array is left alone here."""
+    wav = np.array(wav, copy=True)
+    if not np.issubdtype(wav.dtype, np.floating):
+        wav = wav.astype(np.float64)
+    if wav.size:
+        wav *= 32767 / max(0.01, np.max(np.abs(wav)))
+    return wav.astype(np.int16)
 
 
 def save_wav(wav, path):

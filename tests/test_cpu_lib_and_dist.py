@@ -34,12 +34,47 @@ def test_hparams_struct_matches_header():
     from tacotron_amd import _lib
     from tacotron_amd.hparams import HParams
     s = _lib.make_hparams_struct(HParams())
-    assert ctypes.sizeof(s) == 37 * 4
+    assert ctypes.sizeof(s) == 38 * 4 and s.struct_size == 38 * 4
     assert (s.num_chars, s.prenet_depth2, s.encoder_K, s.decoder_proj2, s.hop_length, s.win_length) == (95, 128, 16, 80, 300, 1200)
     hdr = open(os.path.join(ROOT, 'include', 'taco.h')).read()
     body = hdr[hdr.index('typedef struct TacoHParams {'):hdr.index('} TacoHParams;')]
-    fields = re.findall(r'^\s*(?:int32_t|float)\s+(\w+);', body, flags=re.M)
-    assert fields == [f[0] for f in _lib.TacoHParams._fields_]
+    fields = re.findall(r'^\s*(u?int32_t|float)\s+(\w+);', body, flags=re.M)
+    ctype = {'uint32_t': ctypes.c_uint32, 'int32_t': ctypes.c_int32, 'float': ctypes.c_float}
+    assert [(n, ctype[t]) for t, n in fields] == list(_lib.TacoHParams._fields_)
+    assert fields[0] == ('uint32_t', 'struct_size')
+
+
+def test_integration_stub_struct_matches_header():
+    """The reference-side binding shown in INTEGRATION.md declares TacoHParams field for field as include/taco.h does:
+    the stub's class is extracted from the document, executed, and compared with the header (names, types, order)."""
+    import ctypes
+    md = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    start = md.index('class TacoHParams(ctypes.Structure):')
+    stub = md[start:md.index('class TacoWeightEntry(ctypes.Structure):', start)]
+    ns = {'ctypes': ctypes}
+    exec(stub, ns)
+    hdr = open(os.path.join(ROOT, 'include', 'taco.h')).read()
+    body = hdr[hdr.index('typedef struct TacoHParams {'):hdr.index('} TacoHParams;')]
+    ctype = {'uint32_t': ctypes.c_uint32, 'int32_t': ctypes.c_int32, 'float': ctypes.c_float}
+    want = [(n, ctype[t]) for t, n in re.findall(r'^\s*(u?int32_t|float)\s+(\w+);', body, flags=re.M)]
+    assert list(ns['TacoHParams']._fields_) == want and len(want) == 38
+    from tacotron_amd import _lib
+    assert ctypes.sizeof(ns['TacoHParams']) == ctypes.sizeof(_lib.TacoHParams)
+
+
+def test_create_rejects_wrong_struct_size():
+    """A binding built against an older (shorter) or newer header is refused before any other field is read."""
+    import ctypes
+    from tacotron_amd import _lib
+    from tacotron_amd.hparams import HParams
+    lib = _lib.load_library()
+    for size in (0, 33 * 4, 37 * 4, 39 * 4):
+        s = _lib.make_hparams_struct(HParams())
+        s.struct_size = size
+        entries = (_lib.TacoWeightEntry * 1)()
+        h = ctypes.c_void_p()
+        assert lib.taco_create(ctypes.byref(s), entries, 0, 0, ctypes.byref(h)) < 0
+        assert 'struct_size' in _lib.last_error() and not h.value
 
 
 def test_create_rejects_non_default_pooling():

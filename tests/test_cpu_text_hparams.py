@@ -41,6 +41,82 @@ def test_hparams_defaults_and_parse():
     assert HParams().max_iters == 200                     # instances do not share state
 
 
+def test_hparams_match_reference_literals():
+    """tests/golden/hparams_goldens.json holds the keyword literals of /root/reference/hparams.py:7-68, read by
+    importing that file (tests/golden/make_refpin_goldens.py): every default of the product, name by name."""
+    from tacotron_amd.hparams import HParams
+    g = json.load(open(os.path.join(HERE, 'golden', 'hparams_goldens.json')))
+    hp = HParams()
+    mine = hp.values()
+    assert set(mine) == set(g['values']), set(mine) ^ set(g['values'])
+    for k, v in g['values'].items():
+        assert mine[k] == v and type(mine[k]) is type(v), (k, mine[k], v)
+        assert hp.get(k) == v and getattr(hp, k) == v
+    assert list(hp.stft_params()) == g['stft_params']            # audio.py:150-164 evaluated by the reference
+    assert len(g['values']) == 44
+
+
+def _dsp_goldens():
+    return np.load(os.path.join(HERE, 'golden', 'host_dsp_goldens.npz'))
+
+
+@pytest.mark.parametrize('side', ['product', 'oracle'])
+def test_host_dsp_matches_reference_outputs(side):
+    """tests/golden/host_dsp_goldens.npz: inputs and outputs of the reference's own numpy/scipy helpers
+    (tools/audio.py:15-17,81-88,91-116,212-224,254-274), produced by importing that file
+    (tests/golden/make_refpin_goldens.py). Product and oracle are each compared with the reference's outputs."""
+    g = _dsp_goldens()
+    from oracle import taco_oracle as O
+    from tacotron_amd.hparams import HParams
+    from tacotron_amd.tools import audio
+    hp = HParams()
+    if side == 'product':
+        pre_inv, pre, ep = audio.pre_emphasis_inv, audio.pre_emphasis, audio.find_endpoint
+        to_i16, db2amp, amp2db = audio.wav_to_int16, audio._db_to_amp, audio._amp_to_db
+        norm, norm_inv = audio._normalize, audio._normalize_inv
+    else:
+        pre_inv, pre = O.pre_emphasis_inv, O.pre_emphasis
+        ep = lambda w, **k: O.find_endpoint(w, hp.sample_rate, **k)
+        to_i16 = O.wav_to_int16
+        db2amp = lambda x: np.power(10.0, x * 0.05)
+        amp2db = lambda x: 20 * np.log10(np.maximum(1e-5, x))
+        norm = lambda s: O._normalize(s, hp)
+        norm_inv = lambda s: np.clip(s, 0, 1) * -float(hp.min_level_db) + hp.min_level_db
+    # linear recurrences: same operations in the same order as lfilter -> equal to the last bits (allow 1e-12 relative)
+    for x, want in ((g['pre_x'], g['pre_emphasis_inv']), (g['pre_x32'], g['pre_emphasis_inv_x32'])):
+        got = pre_inv(x)
+        assert got.dtype == np.float64 and np.allclose(got, want, rtol=1e-12, atol=1e-12)
+    assert np.allclose(pre(g['pre_x']), g['pre_emphasis'], rtol=1e-12, atol=1e-12)
+    for i in range(int(g['n_endpoint_cases'])):
+        assert ep(g['ep_wav_%d' % i]) == int(g['ep_out_%d' % i]), i
+    assert ep(g['ep_wav_7'], threshold_db=-30, min_silence_sec=0.5) == int(g['ep_out_7_m30_05'])
+    assert np.array_equal(db2amp(g['db_in']), g['db_to_amp'])
+    assert np.array_equal(amp2db(g['amp_in']), g['amp_to_db'])
+    assert np.array_equal(norm(g['norm_in']), g['normalize'])
+    assert np.array_equal(norm_inv(g['norm_inv_in']), g['normalize_inv'])
+    for i in range(int(g['n_save_wav_cases'])):
+        assert np.array_equal(to_i16(g['sw_in_%d' % i]), g['sw_pcm_%d' % i]), i
+        assert int(g['sw_rate_%d' % i]) == hp.sample_rate
+    if side == 'oracle':
+        # the vocoder's input amplitudes (audio.py:53 / :63-64): the oracle's fused form against the reference's chain
+        got = O.denorm_db_to_amp_pow(g['norm_inv_in'], hp)
+        assert np.allclose(got, g['spec_amp_pow'], rtol=1e-14, atol=0)
+
+
+def test_save_wav_file_holds_reference_pcm(tmp_path):
+    """The file save_wav writes carries exactly the int16 samples the reference handed to librosa.output.write_wav."""
+    import wave
+    from tacotron_amd.tools import audio
+    g = _dsp_goldens()
+    for i in range(int(g['n_save_wav_cases'])):
+        p = str(tmp_path / ('a%d.wav' % i))
+        audio.save_wav(g['sw_in_%d' % i].copy(), p)
+        with wave.open(p) as f:
+            assert f.getframerate() == int(g['sw_rate_%d' % i]) and f.getsampwidth() == 2 and f.getnchannels() == 1
+            pcm = np.frombuffer(f.readframes(f.getnframes()), '<i2')
+        assert np.array_equal(pcm, g['sw_pcm_%d' % i])
+
+
 def test_weight_specs_and_initialisers():
     from tacotron_amd.hparams import HParams
     from tacotron_amd.weights import init_weights, variable_specs, check_weights, num_params, save_npz, load_npz
