@@ -20,6 +20,10 @@ Extra objects on the JSON line:
   to_wav       - the same job through the 60-iteration Griffin-Lim (BASELINE.json configs[2], per GPU), timed with
                  the same barrier / max-over-ranks protocol (`mel_linear` instead when --to-wav makes that the headline).
   latency      - p50 wall time of one utterance (B=1) and of one batch alone, to mel+linear and to the waveform.
+  long_form    - BASELINE.json configs[3] (T_in=400, max_iters=400: 2000 frames per utterance) at B=1 and B=32: frames/s,
+                 us per decoder step, and the attention-bound roofline of its decode loop on (W_step + B*2*400*1024) B/step.
+  chain        - the decoder's dependency-chain roofline: S steps x 11 dependent hand-offs x the all-to-all hand-off time
+                 measured in this process by taco_debug_handoff_probe; the launch and the B=1 latency as fractions of it.
   gpu_max_hw_queues, value_at_inherited_hw_queues - the hardware-queue setting the figure was taken at, and the
                  headline leg repeated (child process) at the setting this process inherited.
 """
@@ -139,6 +143,34 @@ def cpu_baseline(hp, weights, T_in, S, budget_s=15.0):
                       % (n, B, T_in, S, el)}
 
 
+def under_profiler():
+    """rocprofv3 (and anything else that preloads a tool library) has initialised the GPU before main() runs: such a
+    process must not start another program (fork + exec). The legs that need a child process are skipped then."""
+    env = os.environ
+    if any(k.startswith(('ROCPROFILER_', 'ROCP_', 'ROCPROF_')) for k in env):
+        return True
+    return any(t in env.get('LD_PRELOAD', '') for t in ('rocprof', 'roctracer', 'rocprofiler'))
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N` as a
+    CHILD process, before this process has touched the GPU, relay rank 0's JSON line and leave with the child's code."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cp = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in cp.stdout.splitlines() if l.startswith('{')]
+    for l in cp.stdout.splitlines():
+        if not l.startswith('{'):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    raise SystemExit(cp.returncode if cp.returncode else (0 if lines else 1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -159,9 +191,23 @@ def main():
     ap.add_argument('--keep-hw-queues', action='store_true', help='do not raise GPU_MAX_HW_QUEUES to 8')
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        if under_profiler():
+            raise SystemExit('bench.py --gpus %d under a profiler: launch the ranks with torch.distributed.run yourself '
+                             '(a process whose GPU the profiler has initialised must not start another)' % args.gpus)
+        self_launch(args)
+    if int(os.environ.get('WORLD_SIZE', 1)) != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%s: launch with --nproc-per-node %d'
+                         % (args.gpus, os.environ.get('WORLD_SIZE', '1 (unset)'), args.gpus))
+
     inherited_leg = None
+    profiled = under_profiler()
+    if profiled and not args.no_extras and not args.keep_hw_queues:
+        inherited_leg = {'skipped': 'profiler'}          # (no child process from a process the profiler has initialised)
     if (int(os.environ.get('RANK', 0)) == 0 and int(os.environ.get('WORLD_SIZE', 1)) == 1 and not args.no_extras and not args.keep_hw_queues and
-            os.environ.get('GPU_MAX_HW_QUEUES') != HWQ_INHERITED):
+            not profiled and os.environ.get('GPU_MAX_HW_QUEUES') != HWQ_INHERITED):
         # The same headline leg at the hardware-queue count this process inherited (the GPU box exports 4), in a child
         # process that runs to its end BEFORE this process touches the GPU: a process that has initialised the GPU
         # must not start (fork + exec) another program on this pool.
@@ -342,6 +388,11 @@ def main():
                 'batch_mel_linear': lat_ms if not args.to_wav else p50_latency(eng, ids, lens, False, out, 5),
                 'batch_to_wav': lat_ms if args.to_wav else p50_latency(eng, ids, lens, True, out, 5),
                 'batch': B}
+            # BASELINE.json configs[4]: B=1 with the per-stage step chain captured into a hipGraph (decode mode 1)
+            eng.set_decode_graph(1)
+            res['latency']['b1_hipgraph_mel_linear'] = p50_latency(eng, ids[:1], lens[:1], False, o1, 9)
+            res['latency']['b1_hipgraph_to_wav'] = p50_latency(eng, ids[:1], lens[:1], True, o1, 9)
+            eng.set_decode_graph(args.decode_mode)
 
     if rank == 0 and not args.no_roofline:
         work = family_work(hp, B, T_in, S)
@@ -408,8 +459,101 @@ def main():
             res['decode_loop'] = {'kernel': loop, 'ms': fam[loop]['ms'], 'us_per_decoder_step': 1e6 * s2 / S,
                                   'us_per_decoder_step_live': (1e3 * live_ms / live_n / S) if live_n else None,
                                   'achieved_GBps': amt / s2 / 1e9, 'frac_of_hbm': amt / s2 / 1e9 / HBM_PEAK_GBS}
+        r0['traffic_source'] = 'profiles/traffic.json (static: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes)'
+        try:
+            busy = json.load(open(os.path.join(ROOT, 'profiles', 'mfma_busy.json')))
+            for r in res['rooflines']:
+                if r['kernel'] in busy:
+                    r['counters'] = busy[r['kernel']]     # (static: SQ counter passes of profiles/r03, see profiles/README.md)
+        except Exception:
+            pass
+
+    if rank == 0 and not args.no_roofline and not args.no_extras and args.decode_mode == 2:
+        # ---- dependency-chain roofline of the decoder: a decoder step is 11 dependent all-to-all
+        # hand-offs among a tile's 32 workgroups; the price of one such hand-off with nothing else in it is measured
+        # here, in this process, on the idle chip (taco_debug_handoff_probe: 32 workgroups, 4000 dependent rounds)
+        torch.cuda.synchronize()
+        t_h = min(eng.handoff_probe(4000) for _ in range(3))
+        EDGES = 11
+        chain_ms = 1e-3 * S * EDGES * t_h
+
+        def decode_ms(n_ids, n_lens, o, s_iters):
+            eng.timing_begin('dec_persistent')
+            eng.synthesize(n_ids, n_lens, max_iters=s_iters, to_wav=False, out=o)
+            n, ms = eng.timing_end()
+            return ms / max(n, 1)
+        o1 = {}
+        eng.synthesize(ids[:1], lens[:1], max_iters=S, to_wav=False, out=o1)
+        b1_dec = min(decode_ms(ids[:1], lens[:1], o1, S) for _ in range(3))
+        dl = res.get('decode_loop', {})
+        res['chain'] = {
+            'bound': 'dependency chain', 'handoff_us': t_h, 'edges_per_step': EDGES, 'steps': S,
+            'chain_ms_per_launch': chain_ms, 'chain_us_per_step': EDGES * t_h,
+            'measured': 'taco_debug_handoff_probe: 32 workgroups (one per CU), 4000 dependent all-to-all rounds of '
+                        '32 x 1 KB {value, tag} granules, idle chip, best of 3',
+            'launch_ms_alone': dl.get('ms'), 'frac_alone': (chain_ms / dl['ms']) if dl.get('ms') else None,
+            'launch_ms_live': (live_ms / live_n) if live_n else None,
+            'frac_live': (chain_ms * live_n / live_ms) if live_n else None,
+            'b1_decode_ms': b1_dec, 'b1_frac': chain_ms / b1_dec if b1_dec else None,
+            'b1_latency_mel_linear_ms': res.get('latency', {}).get('b1_mel_linear')}
+
+        # ---- BASELINE.json configs[3]: long-form, T_in = 400 characters, max_iters = 400 (2000 frames per utterance)
+        T2, S2 = 400, 400
+        ids2, lens2 = synth_ids(np.random.default_rng(3), B, T2, ragged=False)
+        ids2 = torch.from_numpy(ids2).to(eng.device)
+        lens2 = torch.from_numpy(lens2).to(eng.device)
+        w_step, attn2 = decoder_step_bytes(hp, B, T2)
+        _, attn2_1 = decoder_step_bytes(hp, 1, T2)
+        lf = {'workload': 'BASELINE.json configs[3]: long-form, T_in=%d, max_iters=%d (%d frames per utterance), fp32, '
+                          'mel+linear' % (T2, S2, S2 * hp.outputs_per_step),
+              'attention_bytes_per_step': {'b1': w_step + attn2_1, 'batch': w_step + attn2}}
+        outs2 = [{} for _ in engines]
+        for i, e in enumerate(engines):
+            e.synthesize(ids2, lens2, max_iters=S2, to_wav=False, out=outs2[i])      # workspace / buffers
+        torch.cuda.synchronize()
+        eng.set_persist_budget(0)
+        n3 = 4 * len(engines)
+        t0 = time.perf_counter()
+        for i in range(n3):
+            engines[i % len(engines)].synthesize(ids2, lens2, max_iters=S2, to_wav=False, out=outs2[i % len(engines)])
+        torch.cuda.synchronize()
+        el3 = time.perf_counter() - t0
+        for e in engines:
+            e.decode_status()
+        o2 = {}
+        eng.synthesize(ids2[:1], lens2[:1], max_iters=S2, to_wav=False, out=o2)
+        d1 = min(decode_ms(ids2[:1], lens2[:1], o2, S2) for _ in range(3))
+        dB = min(decode_ms(ids2, lens2, outs2[0], S2) for _ in range(2))
+
+        def lroof(bytes_per_step, ms):
+            ach = bytes_per_step * S2 / (ms * 1e-3) / 1e9
+            return {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                    'us_per_decoder_step': 1e3 * ms / S2, 'decode_ms': ms,
+                    'chain_frac': 1e-3 * S2 * EDGES * t_h / ms}
+        lf['batch'] = dict(B=B, value=B * S2 * hp.outputs_per_step * n3 / el3, unit='mel frames/s',
+                           ms_per_step=1e3 * el3 / n3, steps=n3, batches_in_flight=len(engines),
+                           p50_batch_latency_ms=p50_latency(eng, ids2, lens2, False, outs2[0], 3),
+                           decode_roofline=lroof(w_step + attn2, dB))
+        lat1 = p50_latency(eng, ids2[:1], lens2[:1], False, o2, 5)
+        lf['b1'] = dict(B=1, p50_latency_ms=lat1, value=S2 * hp.outputs_per_step / (lat1 * 1e-3), unit='mel frames/s',
+                        p50_latency_to_wav_ms=p50_latency(eng, ids2[:1], lens2[:1], True, o2, 3),
+                        decode_roofline=lroof(w_step + attn2_1, d1))
+        res['long_form'] = lf
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(hp, weights, T_in, S)
+        if not args.no_extras:
+            # BASELINE.json configs[0] (synthesizer.py:37-45): one utterance through the 60-iteration Griffin-Lim on the CPU
+            from oracle import taco_oracle as O
+            w32 = O.cast_weights(weights, np.float32)
+            ids1, lens1 = synth_ids(np.random.default_rng(0), 1, T_in, ragged=False)
+            t0 = time.time()
+            f = O.tacotron_forward(ids1, lens1, w32, hp, dtype=np.float32, max_iters=S)
+            O.spectrogram_tensorflow_inv(f['linear'][0], hp, dtype=np.float32)
+            res['cpu_baseline']['b1_to_wav_ms'] = 1e3 * (time.time() - t0)
+            res['cpu_baseline']['b1_sample'] = ('1 run: B=1, T_in=%d, %d decoder steps, mel+linear, %d Griffin-Lim '
+                                                'iterations (BASELINE.json configs[0]), fp32 numpy oracle'
+                                                % (T_in, S, hp.griffin_lim_iters))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

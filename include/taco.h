@@ -212,6 +212,9 @@ int taco_set_decode_graph(taco_handle h, int32_t mode);
  * vocoder's full-chip launches then always find three quarters of the CUs (measured 3.04 -> 3.28 M frames/s to the
  * waveform at B = 32, six batches in flight). A single decode larger than the budget is still admitted, alone. */
 int taco_set_persist_budget(int32_t device, int32_t workgroups);
+/* The value last set for `device` (0 if never set). The knob is per process and device, not per handle: a caller that
+ * changes it for a job reads it first and puts it back afterwards (tacotron_amd/pipeline.py does). */
+int32_t taco_get_persist_budget(int32_t device);
 
 /* Synchronous check of the last persistent decode (reads a few device words; call after the stream has been
  * synchronised): <0 if one of its bounded inter-workgroup waits timed out, in which case its outputs are invalid.
@@ -226,6 +229,13 @@ int taco_decode_status(taco_handle h);
 /* Test hook (no reference counterpart): sets the handle's sticky abort word as a timed-out persistent decode would,
  * so the failure path above can be exercised without hanging a GPU. */
 int taco_debug_poison_decoder(taco_handle h);
+
+/* Measurement hook (no reference counterpart): the price of ONE dependency edge of the persistent decoder's step on
+ * `device`, right now: `rounds` dependent all-to-all hand-offs among 32 workgroups (one per CU), each publishing 1 KB of
+ * {value, tag} granules and gathering all 32 KB before it may publish again - the transport of the decoder kernel with
+ * no arithmetic in it. bench.py multiplies it by the 11 edges of a step for the decoder's dependency-chain roofline.
+ * Allocates and frees its own few KB; synchronous. */
+int taco_debug_handoff_probe(int32_t device, int32_t rounds, double* us_per_handoff);
 
 /* Test hook (no reference counterpart): one launch of the dense / SAME-conv1d implicit-GEMM
  * kernel, C[m,n] = (act(sum_{j,c} X[b,t+j-padl,c] W[j*Cin+c,n] + bias[n])) * scale[n] + shift[n]

@@ -1156,18 +1156,21 @@ static int gl_impl(taco_ctx* c, const float* linear, int B, int T, int iters, fl
     float* fb = ws.take<float>(M * hp.win_length);
     if (!ws.ok()) return fail("taco_griffin_lim: workspace too small");
     GLPlan p{hp.n_fft, hp.hop_length, hp.win_length, hp.num_freq, c->twiddle, c->window, c->gl_image};
+    gl_read_switches(p);                                    // (experiment switches: once per call, not per launch)
+    p.prepared = true;                                      // taco_create set the kernels' attributes on this device
     launch_gl_mag(linear, mag, M * hp.num_freq, hp.min_level_db, hp.ref_level_db, hp.power, s, tm);
+    int chain_rc = 0;
     auto chain = [&](int b0, int nb, hipStream_t st, Timing* t) {
         const size_t r0 = (size_t)b0 * T;
         float* a0 = fa + r0 * hp.win_length;
         float* a1 = fb + r0 * hp.win_length;
         const float* mg = mag + r0 * hp.num_freq;
         int state = 0;                                      // what `cur` holds: frames, or run records (kernels.h)
-        launch_gl_iter(p, a0, mg, a0, nb, T, 1, st, t, false, nullptr, &state);   // y0 = istft(mag, zero phase) (audio.py:191)
+        chain_rc |= launch_gl_iter(p, a0, mg, a0, nb, T, 1, st, t, false, nullptr, &state);   // y0 = istft(mag, zero phase) (audio.py:191)
         float* cur = a0;
         float* nxt = a1;
         for (int i = 0; i < iters; ++i) {                   // audio.py:192-195
-            launch_gl_iter(p, cur, mg, nxt, nb, T, 0, st, t, false, nullptr, &state);
+            chain_rc |= launch_gl_iter(p, cur, mg, nxt, nb, T, 0, st, t, false, nullptr, &state);
             std::swap(cur, nxt);
         }
         launch_gl_ola(p, cur, wav + (size_t)b0 * ((size_t)(T - 1) * hp.hop_length + hp.win_length), nb, T, st, t,
@@ -1191,9 +1194,10 @@ static int gl_impl(taco_ctx* c, const float* linear, int B, int T, int iters, fl
         }
         if (!c->gl_fork && hipEventCreateWithFlags(&c->gl_fork, hipEventDisableTiming) != hipSuccess) G = 1;
     }
+    const char* kStateErr = "taco_griffin_lim: internal error: run records handed to a kernel that reads frames";
     if (G <= 1) {
         chain(0, B, s, tm);
-        return 0;
+        return chain_rc ? fail("%s", kStateErr) : 0;
     }
     HIP_OK(hipEventRecord(c->gl_fork, s));
     for (int g = 1; g < G; ++g) {
@@ -1204,7 +1208,7 @@ static int gl_impl(taco_ctx* c, const float* linear, int B, int T, int iters, fl
     }
     chain(0, (int)((long)B / G), s, nullptr);
     for (int g = 1; g < G; ++g) HIP_OK(hipStreamWaitEvent(s, c->gl_join[g - 1], 0));
-    return 0;
+    return chain_rc ? fail("%s", kStateErr) : 0;
 }
 
 // numpy/librosa flavour (audio.py:44-55,167-181) up to, not including, pre_emphasis_inv
@@ -1219,15 +1223,16 @@ static int gl_librosa_impl(taco_ctx* c, const float* linear, const float* phase_
     if (!ws.ok()) return fail("taco_griffin_lim_librosa: workspace too small");
     GLPlan p{hp.n_fft, hp.hop_length, hp.win_length, hp.num_freq, c->twiddle, c->window, c->gl_image};
     launch_gl_mag(linear, mag, M * hp.num_freq, hp.min_level_db, hp.ref_level_db, hp.power, s, tm);
-    launch_gl_iter(p, fa, mag, fa, B, T, 1, s, tm, true, phase_u);   // y = istft(S * angles) (audio.py:175-177)
+    p.prepared = true;
+    int rc = launch_gl_iter(p, fa, mag, fa, B, T, 1, s, tm, true, phase_u);   // y = istft(S * angles) (audio.py:175-177)
     float* cur = fa;
     float* nxt = fb;
     for (int i = 0; i < iters; ++i) {                                // audio.py:178-180
-        launch_gl_iter(p, cur, mag, nxt, B, T, 0, s, tm, true, nullptr);
+        rc |= launch_gl_iter(p, cur, mag, nxt, B, T, 0, s, tm, true, nullptr);
         std::swap(cur, nxt);
     }
     launch_gl_ola_norm(p, cur, wav, B, T, s, tm);
-    return 0;
+    return rc ? fail("taco_griffin_lim_librosa: internal error: bad vocoder state") : 0;
 }
 
 extern "C" int taco_griffin_lim_librosa(taco_handle h, const float* linear, const float* phase_u, int32_t B, int32_t T,
@@ -1314,16 +1319,19 @@ extern "C" int taco_griffin_lim_noalloc(taco_handle h, const float* linear, int3
     float* fb = cv.take<float>(M * hp.win_length);
     if (!cv.ok()) return fail("taco_griffin_lim_noalloc: static scratch too small for these hparams");
     GLPlan p{hp.n_fft, hp.hop_length, hp.win_length, hp.num_freq, h->twiddle, h->window, h->gl_image};
+    gl_read_switches(p);
+    p.prepared = true;             // (taco_create set the kernels' attributes on this device: no set-up call from here)
     launch_gl_mag(linear, mag, M * hp.num_freq, hp.min_level_db, hp.ref_level_db, hp.power, s, nullptr);
     int state = 0;
-    launch_gl_iter(p, fa, mag, fa, B, T, 1, s, nullptr, false, nullptr, &state);
+    int rc = launch_gl_iter(p, fa, mag, fa, B, T, 1, s, nullptr, false, nullptr, &state);
     float* cur = fa;
     float* nxt = fb;
     for (int i = 0; i < iters; ++i) {
-        launch_gl_iter(p, cur, mag, nxt, B, T, 0, s, nullptr, false, nullptr, &state);
+        rc |= launch_gl_iter(p, cur, mag, nxt, B, T, 0, s, nullptr, false, nullptr, &state);
         std::swap(cur, nxt);
     }
     launch_gl_ola(p, cur, wav, B, T, s, nullptr, state);
+    if (rc) return fail("taco_griffin_lim_noalloc: internal error: run records handed to a kernel that reads frames");
     return check_launch("taco_griffin_lim_noalloc");
 }
 
@@ -1393,6 +1401,12 @@ extern "C" int taco_set_persist_budget(int32_t device, int32_t workgroups) {
     return 0;
 }
 
+extern "C" int32_t taco_get_persist_budget(int32_t device) {
+    std::lock_guard<std::mutex> lk(g_persist_mu);
+    auto it = g_persist_budget.find(device);
+    return it != g_persist_budget.end() ? it->second : 0;
+}
+
 extern "C" int taco_set_decode_graph(taco_handle h, int32_t mode) {
     if (!h) return fail("taco_set_decode_graph: null handle");
     if (mode < 0 || mode > 2) return fail("taco_set_decode_graph: mode must be 0, 1 or 2");
@@ -1447,6 +1461,45 @@ extern "C" int taco_debug_poison_decoder(taco_handle h) {
     const unsigned one = 1u;
     HIP_OK(hipMemcpy(reinterpret_cast<unsigned*>(h->sync_words) + PD_SYNC_STICKY, &one, 4, hipMemcpyHostToDevice));
     return 0;
+}
+
+extern "C" int taco_debug_handoff_probe(int32_t device, int32_t rounds, double* us_per_handoff) {
+    if (!us_per_handoff || rounds < 1 || rounds > (1 << 20)) return fail("taco_debug_handoff_probe: bad argument");
+    HIP_OK(hipSetDevice(device));
+    int cus = 0;
+    HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    if (cus < 32) return fail("taco_debug_handoff_probe: needs 32 CUs for its 32 co-resident workgroups, device has %d", cus);
+    const size_t region_bytes = 2u * 32u * 256u * 4u, total = region_bytes + 256 + 128;
+    char* buf = nullptr;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&buf), total));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    float ms = 0.f;
+    unsigned abort_h[4] = {0, 0, 0, 0};
+    auto body = [&]() -> int {
+        HIP_OK(hipEventCreate(&e0));
+        HIP_OK(hipEventCreate(&e1));
+        for (int pass = 0; pass < 2; ++pass) {              // (first pass: code object load, clocks)
+            HIP_OK(hipMemsetAsync(buf, 0, total, nullptr));
+            HIP_OK(hipEventRecord(e0, nullptr));
+            launch_handoff_probe(reinterpret_cast<float*>(buf), (unsigned)region_bytes, rounds,
+                                 reinterpret_cast<unsigned*>(buf + region_bytes), reinterpret_cast<float*>(buf + region_bytes + 256),
+                                 nullptr);
+            HIP_OK(hipEventRecord(e1, nullptr));
+            HIP_OK(hipEventSynchronize(e1));
+            HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        HIP_OK(hipMemcpy(abort_h, buf + region_bytes, sizeof(abort_h), hipMemcpyDeviceToHost));
+        return 0;
+    };
+    rc = body();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
+    if (rc) return rc;
+    if (abort_h[0]) return fail("taco_debug_handoff_probe: a bounded wait ran out (the 32 workgroups were not co-resident?)");
+    *us_per_handoff = 1e3 * (double)ms / rounds;
+    return check_launch("taco_debug_handoff_probe");
 }
 
 extern "C" int taco_debug_conv_gemm(const float* X, int32_t ldx, int32_t M, int32_t T, int32_t Cin, int32_t taps,

@@ -777,6 +777,66 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(DecPersistAr
 #undef PD_BIAS
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Hand-off probe (measurement only, taco_debug_handoff_probe): the transport of ONE dependency edge of the decoder
+// step, with nothing else in it. 32 workgroups, one per CU like a tile's group; every round each workgroup publishes a
+// 1 KB piece of a 256 x 16 activation tile as {value, tag} granules (wave 0, sc1 stores) and then gathers all 32 pieces
+// (32 KB, the four waves a quarter each, sc1 loads, retried until every tag matches), reduces across its waves through
+// LDS as pd_mma does, and only then publishes the next round's piece, whose value depends on what it gathered: a chain
+// of `rounds` dependent all-to-all hand-offs. Its time per round is the floor of one edge of the step on this device
+// at this moment: bench.py prices the step's dependency chain with it (11 edges per step).
+__global__ __launch_bounds__(PD_THREADS) void pd_handoff_probe_kernel(float* region, unsigned region_bytes, int rounds,
+                                                                      unsigned* abort_word, float* sink) {
+    __shared__ f32x4 red[PD_WAVES * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(region, 0, region_bytes, 0x00020000);
+    Spin spin{abort_word, 0u, false, 0u, 0ull};
+#ifdef PD_STAMPS
+    spin.st_lds = nullptr; spin.stamp_i = 0; spin.stamp_on = false;
+#endif
+    f32x4 mine = {1.f, 2.f, 3.f, 4.f};
+    constexpr unsigned PIECE = 32u * 8u;                     // floats per piece: 32 lanes x one granule quad
+    for (int r = 0; r < rounds; ++r) {
+        const unsigned tag = (unsigned)r + 1u;
+        const unsigned buf = (unsigned)(r & 1) * 32u * PIECE;
+        if (wave == 0) pd_stg(rs, buf + (unsigned)j * PIECE + (unsigned)(lane & 31) * 8u, mine, tag, lane < 32);
+        GQuad g[4] = {};
+        bool have[4] = {false, false, false, false};
+        spin.begin(tag);
+        while (true) {
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (!have[i]) g[i] = pd_ldg(rs, buf + (unsigned)(wave + 4 * (2 * i + (lane >> 5))) * PIECE + (unsigned)(lane & 31) * 8u);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (!have[i]) {
+                    have[i] = __all(gq_ok(g[i], tag));
+                    ok = ok && have[i];
+                }
+            if (ok || spin.give_up()) break;
+        }
+        f32x4 acc = gq_val(g[0]) + gq_val(g[1]) + gq_val(g[2]) + gq_val(g[3]);
+        __syncthreads();
+        red[wave * 64 + lane] = acc;
+        __syncthreads();
+        if (wave == 0) {
+            f32x4 v = red[lane];
+#pragma unroll
+            for (int ww = 1; ww < PD_WAVES; ++ww) v += red[ww * 64 + lane];
+            mine = v * (1.f / 1024.f) + f32x4{1.f, 1.f, 1.f, 1.f};
+        }
+    }
+    if (wave == 0 && lane == 0) sink[j] = mine.x;
+}
+
+int launch_handoff_probe(float* region, unsigned region_bytes, int rounds, unsigned* abort_word, float* sink,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(pd_handoff_probe_kernel, dim3(32), dim3(PD_THREADS), 0, s, region, region_bytes, rounds,
+                       abort_word, sink);
+    return 0;
+}
+
 // LDS of a launch: sized for its fullest tile (the first one), whose workgroups hold the largest parts
 size_t dec_persistent_lds_bytes(int T_in, int B, int* lds_keys, int* lds_vals) {
     const size_t cap = 160 * 1024;

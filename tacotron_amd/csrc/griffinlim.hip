@@ -1046,11 +1046,17 @@ std::vector<float> gl_lds_image(const std::vector<float>& tw, const std::vector<
 // Frames per workgroup of gl_iter2_kernel for a job of B utterances of T frames: whole pairs per wave only (8 or 16
 // frames); the shorter run when it does not cost another round of workgroups over the chip's 512 places (two per CU):
 // a workgroup lives for about one gather plus one transform time per pair, and a gather takes about as long as a pair.
-static int gl2_run(int B, int T) {
-    if (const char* e = getenv("TACO_GL_RUN")) {         // experiments: 8 or 16
-        const int r = atoi(e);
-        if (r == 8 || r == 16) return r;
-    }
+void gl_read_switches(GLPlan& p) {
+    p.one_frame = getenv("TACO_GL_ONE_FRAME") != nullptr;
+    const char* e = getenv("TACO_GL_FRAME_STATE");
+    p.frame_state = e ? (atoi(e) == 0 ? 0 : 1) : -1;
+    e = getenv("TACO_GL_RUN");
+    const int r = e ? atoi(e) : 0;
+    p.run = (r == 8 || r == 16) ? r : 0;
+}
+
+static int gl2_run(const GLPlan& p, int B, int T) {
+    if (p.run) return p.run;                             // experiments: 8 or 16
     const long slots = 512;
     auto rounds = [&](int r) { return ((long)B * ((T + r - 1) / r) + slots - 1) / slots; };
     return rounds(8) * 2 <= rounds(16) * 3 ? 8 : GL_RUN;
@@ -1060,20 +1066,19 @@ static int gl2_run(int B, int T) {
 // not when its few workgroups have a CU each and the round barriers only lengthen them: GL2_RECORDS_MIN_GRID.
 // TACO_GL_FRAME_STATE=1 keeps the frame state always, =0 takes records whenever the geometry allows (tests compare).
 constexpr long GL2_RECORDS_MIN_GRID = 257;
-static bool gl2_records_ok(int T, int run, long grid) {
+static bool gl2_records_ok(const GLPlan& p, int T, int run, long grid) {
     const int last = T % run;
     if (!(last == 0 || last >= 3)) return false;
     // the records of an utterance must fit where its frames would lie (the caller's buffers are sized for frames):
     // true from T = 4 (runs of 8) / T = 6 (runs of 16) on
     const long runs_per_utt = (T + run - 1) / run;
     if (runs_per_utt * (2 * (1200 - 300) + 300 * run) > (long)T * 1200) return false;
-    if (const char* e = getenv("TACO_GL_FRAME_STATE")) return atoi(e) == 0;
+    if (p.frame_state >= 0) return p.frame_state == 0;
     return grid >= GL2_RECORDS_MIN_GRID;
 }
 
-void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, float* frames_out, int B, int T,
-                    int first, hipStream_t s, Timing* tm, bool librosa, const float* phase_u, int* state) {
-    if (tm) tm->begin(KK_GL_ITER, s);
+int launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, float* frames_out, int B, int T,
+                   int first, hipStream_t s, Timing* tm, bool librosa, const float* phase_u, int* state) {
     // frames per workgroup: as many as keep the y segment within ~24 KB of LDS (2 workgroups per CU and more)
     int run = GL_RUN;
     while (run > 1 && ((size_t)(run - 1) * p.hop + p.win) * 4 > 24 * 1024) --run;
@@ -1081,21 +1086,25 @@ void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, f
     // the iteration of the TF flavour at the default geometry runs two frames per wave (gl_iter2_kernel); the choice
     // depends on the geometry and the flavour only, never on the batch, so an utterance's result does not depend on
     // what it is batched with
-    const bool two = dflt && !librosa && !first && run == GL_RUN && p.lds_image && !getenv("TACO_GL_ONE_FRAME");
+    const bool two = dflt && !librosa && !first && run == GL_RUN && p.lds_image && !p.one_frame;
     // small jobs: shorter runs (down to one frame, or one pair of frames, per wave) until the grid covers the chip
     // twice; the overlap-add order per sample does not depend on the run length, so results are bit-identical
     const int sin = state ? *state : 0;                  // what frames_in holds: 0 = frames, else run records of that run length
+    // run records can only be read by the two-frame kernel; within a chain (same B, T, flavour and switches
+    // throughout) they never reach the other one
+    if (sin && !two) return -1;
+    if (tm) tm->begin(KK_GL_ITER, s);
     if (two) {
-        run = sin ? sin : gl2_run(B, T);
+        run = sin ? sin : gl2_run(p, B, T);
     } else {
         while (run > GL_WAVES && (long)B * ((T + run - 1) / run) < 512) run -= GL_WAVES;
     }
     const int runs_per_utt = (T + run - 1) / run;
-    gl_prepare_device();
+    if (!p.prepared) gl_prepare_device();
     const dim3 grid((unsigned)(B * runs_per_utt));
     if (two) {
         // the state written: run records when the caller can take them (it passes `state`) and the geometry allows
-        const int sout = sin || (state && gl2_records_ok(T, run, (long)B * runs_per_utt)) ? 1 : 0;
+        const int sout = sin || (state && gl2_records_ok(p, T, run, (long)B * runs_per_utt)) ? 1 : 0;
         const size_t lds = (size_t)(((run - 1) * p.hop + p.win + 3) & ~3) * 4 + (size_t)p.win * 4 +
                            (size_t)(FFT_TW + FFT_N / 2 + GL_WAVES * GL2_LDS) * sizeof(cplx) +
                            (sout ? (size_t)(p.win - p.hop) * 4 + 16 : 0);
@@ -1106,10 +1115,6 @@ void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, f
                            p.nbins, run, runs_per_utt);
         if (state) *state = sout ? run : 0;
     } else {
-        if (sin) {                                       // cannot happen within a chain (same B, T, flavour throughout)
-            fprintf(stderr, "taco: launch_gl_iter: run records handed to a kernel that reads frames\n");
-            abort();
-        }
         if (state) *state = 0;
         const size_t lds = (size_t)((((run - 1) * p.hop + p.win + 3) & ~3) + ((p.win + 3) & ~3)) * 4 +
                            (size_t)(FFT_TW + FFT_N / 2 + GL_WAVES * FFT_LDS) * sizeof(cplx);
@@ -1119,6 +1124,7 @@ void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, f
                            p.window, phase_u, B, T, p.hop, p.win, p.nbins, first, run, runs_per_utt);
     }
     if (tm) tm->end(KK_GL_ITER, s);
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------

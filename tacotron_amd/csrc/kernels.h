@@ -154,6 +154,10 @@ struct DecPersistArgs {
     int xcd_pack;             // placement experiment (launcher, TACO_PD_XCD_PACK): see dec_persistent_kernel
 };
 int launch_dec_persistent(DecPersistArgs a, hipStream_t s, Timing* tm);
+// measurement only: `rounds` dependent all-to-all granule hand-offs among 32 workgroups (dec_persistent.hip);
+// region: 2 x 32 x 256 floats, zero-filled; abort_word: 64 zeroed unsigned; sink: 32 floats
+int launch_handoff_probe(float* region, unsigned region_bytes, int rounds, unsigned* abort_word, float* sink,
+                         hipStream_t s);
 // Status words of a handle's persistent decodes, as unsigned indices into DecPersistArgs::sync. [0, 32) are per launch
 // (zeroed by the launcher): abort flag (1 = a bounded wait ran out, 2 = the launch left at once because the handle's
 // sticky word was set), then the workgroup and the tag of the first such wait, and the count of workgroups that
@@ -167,7 +171,15 @@ struct GLPlan {
     const float* window;              // [win] periodic Hann
     const float* lds_image;           // [win floats | FFT_TW + 512 complex]: window, pass-2/3 twiddles and split twiddles
                                       //   exactly as gl_iter2 keeps them in LDS (built once at taco_create), or null
+    // Experiment switches (TACO_GL_ONE_FRAME / TACO_GL_FRAME_STATE / TACO_GL_RUN), read from the environment ONCE per
+    // chain by gl_read_switches and handed down: a change of the environment between two launches of one chain cannot
+    // hand one kernel's state to another.
+    bool one_frame = false;           // keep the one-frame-per-wave kernel
+    int frame_state = -1;             // -1 default rule, 1 frames always, 0 run records whenever the geometry allows
+    int run = 0;                      // 0 default rule, 8 or 16 frames per workgroup
+    bool prepared = false;            // the device's kernel attributes are known to be set (taco_create did): no set-up call
 };
+void gl_read_switches(GLPlan& p);
 void launch_gl_mag(const float* lin, float* mag, size_t n, float min_db, float ref_db, float power,
                    hipStream_t s, Timing* tm);
 // frames_in/out [B*T][win]; first != 0: inverse of (mag, zero phase) only. librosa: the numpy/librosa flavour of the
@@ -177,9 +189,10 @@ void launch_gl_mag(const float* lin, float* mag, size_t n, float min_db, float r
 // 8 / 16 = run records of that many frames, the overlap-added signal as gl_iter2_kernel lays it out, which fits the
 // same buffer) and receives what frames_out holds after the launch; hand it from launch to launch and to launch_gl_ola.
 // All launches of a chain must be given the same B and T.
-void launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, float* frames_out, int B, int T,
-                    int first, hipStream_t s, Timing* tm, bool librosa = false, const float* phase_u = nullptr,
-                    int* state = nullptr);
+// Returns 0, or -1 (nothing launched) when *state names run records but the launch would read frames.
+int launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, float* frames_out, int B, int T,
+                   int first, hipStream_t s, Timing* tm, bool librosa = false, const float* phase_u = nullptr,
+                   int* state = nullptr);
 std::vector<float> gl_lds_image(const std::vector<float>& twiddle, const std::vector<float>& window);
 void gl_prepare_device();   // per-device kernel attributes of gl_iter (idempotent)
 void launch_gl_ola(const GLPlan& p, const float* frames, float* wav, int B, int T, hipStream_t s, Timing* tm,

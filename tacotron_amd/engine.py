@@ -124,6 +124,9 @@ class TacoEngine:
         other batches run beside the decodes."""
         self._check(self.lib.taco_set_persist_budget(int(self.device.index or 0), int(workgroups)))
 
+    def get_persist_budget(self):
+        return int(self.lib.taco_get_persist_budget(int(self.device.index or 0)))
+
     def decode_status(self):
         """After a synchronisation: raises if the last persistent decode hit a barrier timeout."""
         self._check(self.lib.taco_decode_status(self.handle))
@@ -335,6 +338,12 @@ class TacoEngine:
     def kernel_kinds(self):
         n = self.lib.taco_num_kernel_kinds()
         return [self.lib.taco_kernel_name(i).decode() for i in range(n)]
+
+    def handoff_probe(self, rounds=4000):
+        """us per dependent all-to-all granule hand-off among 32 workgroups on this device (include/taco.h)."""
+        us = ctypes.c_double()
+        self._check(self.lib.taco_debug_handoff_probe(int(self.device.index or 0), int(rounds), ctypes.byref(us)))
+        return us.value
 
     def timing_begin(self, kind):
         kinds = self.kernel_kinds()

@@ -393,6 +393,11 @@ def match_variables(entries, hp=None):
     for scope, want in bn_want.items():
         have = bn_have.get(scope, {})
         have_order = sorted(have)
+        if len(have_order) > len(want):
+            # surplus batch-norm scopes: the k-th expected would silently take the k-th present one (all conv-bank BNs
+            # have one shape), i.e. a checkpoint with more layers than hp would load into a different graph
+            problems.append('scope %r holds %d batch_normalization scopes, the graph built from hp has %d' % (
+                scope, len(have_order), len(want)))
         for k, idx in enumerate(sorted(want)):
             src = have[have_order[k]] if k < len(have_order) else {}
             for name, part, shape in want[idx]:
@@ -408,14 +413,29 @@ def match_variables(entries, hp=None):
     return mapping, problems, leftovers
 
 
-def load_tacotron_weights(prefix, hp=None, verify_crc=True, verbose=False, strict=False, report=None):
+# an unclaimed variable whose name has the form of a layer of the graph means the checkpoint was trained with MORE
+# layers than hp describes (highway_5 with num_highway_layers=4, conv_bank_17, an extra prenet_dense_N or GRU cell):
+# loading the rest would compute a different graph than the checkpoint's, so these raise by default
+_LAYER_RE = re.compile(r'(^|/)(highway_\d+|prenet_dense_\d+|conv_bank_\d+|proj_\d+|cell_\d+|batch_normalization(_\d+)?|'
+                       r'gru_cell|bidirectional_rnn|memory_layer|bahdanau_attention)/')
+
+
+def load_tacotron_weights(prefix, hp=None, verify_crc=True, verbose=False, strict=False, report=None,
+                          allow_extra_layers=False):
     """The inference-graph variables of a checkpoint the reference saved (model/tacotron.py:169; restored by
     synthesizer.py:32-34), as the {name relative to model/inference/: float32 array} dict the engine takes. Variables
     are matched by pattern and shape (match_variables). Missing or mis-shaped variables raise, with every problem and
-    every unclaimed variable listed; unclaimed variables alone are reported (`verbose` prints the whole name mapping;
-    `report`, a dict, receives 'mapping', 'leftovers', 'renamed') and raise only under `strict`."""
+    every unclaimed variable listed. Unclaimed variables that look like layers of the graph (highway_N, conv_bank_N,
+    prenet_dense_N, batch_normalization_N, cell_N ...: a checkpoint with more layers than hp) raise too, unless
+    allow_extra_layers; other unclaimed names (really foreign variables) are reported (`verbose` prints the whole
+    name mapping; `report`, a dict, receives 'mapping', 'leftovers', 'renamed') and raise only under `strict`."""
     entries, _ = read_index(prefix)
     mapping, problems, leftovers = match_variables(entries, hp)
+    if not allow_extra_layers:
+        extra = [n for n in leftovers if _LAYER_RE.search(n[len(GRAPH_PREFIX):])]
+        if extra:
+            problems.append('the checkpoint has layers the graph built from hp does not (more layers than hp?): ' +
+                            ', '.join(extra))
     renamed = {k: v for k, v in mapping.items() if v != GRAPH_PREFIX + k}
     if report is not None:
         report.update(mapping=dict(mapping), leftovers=list(leftovers), renamed=renamed)

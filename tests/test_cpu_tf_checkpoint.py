@@ -96,6 +96,26 @@ def test_tacotron_variables_roundtrip_and_diagnostics(tmp_path, capsys):
     with pytest.raises(C.CheckpointError) as ei:
         C.load_tacotron_weights(prefix, hp, strict=True)
     assert 'post_cbhg/extra/kernel' in str(ei.value)
+    # a leftover that has the form of a graph layer = a checkpoint with more layers than hp: refused by default
+    for extra_name, shape in (('post_cbhg/highway_5/H/kernel', (128, 128)),
+                              ('encoder_cbhg/conv_bank/conv_bank_17/conv1d/kernel', (17, 128, 128)),
+                              ('prenet/prenet_dense_3/kernel', (128, 128))):
+        more = dict(full)
+        more[C.GRAPH_PREFIX + extra_name] = np.zeros(shape, np.float32)
+        C.write_checkpoint(prefix, more)
+        with pytest.raises(C.CheckpointError) as ei:
+            C.load_tacotron_weights(prefix, hp)
+        assert extra_name in str(ei.value) and 'more layers' in str(ei.value)
+        assert set(C.load_tacotron_weights(prefix, hp, allow_extra_layers=True)) == set(w)
+    capsys.readouterr()
+    # a surplus batch-norm scope (a 17th conv-bank BN) must not shift the order-based assignment silently
+    more = dict(full)
+    for part in ('gamma', 'beta', 'moving_mean', 'moving_variance'):
+        more[C.GRAPH_PREFIX + 'encoder_cbhg/conv_bank/batch_normalization_16/' + part] = np.ones(128, np.float32)
+    C.write_checkpoint(prefix, more)
+    with pytest.raises(C.CheckpointError) as ei:
+        C.load_tacotron_weights(prefix, hp)
+    assert '17 batch_normalization scopes' in str(ei.value)
     # save side
     C.save_tacotron_weights(prefix, w)
     assert np.array_equal(C.load_tacotron_weights(prefix, hp)['dense/kernel'], w['dense/kernel'])

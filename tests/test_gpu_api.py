@@ -553,7 +553,8 @@ def test_sharded_job_matches_single_device(engine, hp, weights):
     ref = engine.finish(engine.synthesize(ids, lens, max_iters=S, to_wav=True, gl_iters=2), to_wav=True, gl_iters=2)
     pipe = SynthesisPipeline(weights, hp, depth=2, devices=[0, 0])
     try:
-        got = pipe.synthesize_sharded(ids, lens, batch_size=3, max_iters=S, to_wav=True, gl_iters=2)
+        got = pipe.synthesize_sharded(ids, lens, batch_size=3, max_iters=S, to_wav=True, gl_iters=2,
+                                      keys=('mel', 'linear', 'alignments', 'wav'))
         assert len(got) == 10
         for b, r in enumerate(got):
             assert r['steps_run'] == S
@@ -567,5 +568,15 @@ def test_sharded_job_matches_single_device(engine, hp, weights):
         o_half = engine.finish(engine.synthesize(ids[half][:, :lens[half].max()], lens[half], max_iters=S))
         for j, b in enumerate(half):
             assert np.array_equal(got2[b]['mel'], _np(o_half['mel'][j]))
+        # default keys: the waveform alone for a to-waveform job (synthesizer.py:43 fetches nothing else); alignments
+        # of a trimmed job have the batch's own width
+        got3 = pipe.synthesize_sharded(ids, lens, batch_size=4, max_iters=S, to_wav=True, gl_iters=2)
+        assert all(set(r) == {'wav', 'steps_run'} for r in got3)
+        assert all(np.array_equal(r['wav'], _np(ref['wav'][b])) for b, r in enumerate(got3))
+        got4 = pipe.synthesize_sharded(ids, lens, batch_size=10, max_iters=S, trim=True)
+        assert set(got4[0]) == {'mel', 'linear', 'alignments', 'steps_run'}
+        for j, b in enumerate(half):
+            assert got4[b]['alignments'].shape == (int(lens[half].max()), S)
+            assert np.array_equal(got4[b]['alignments'], _np(o_half['alignments'][j]))
     finally:
         pipe.close()

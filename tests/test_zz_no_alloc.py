@@ -48,3 +48,37 @@ def test_noalloc_griffin_lim_matches_workspace_entry(engine, hp):
     # the Python face of it
     lin = rng.uniform(0.2, 1.0, size=(40, hp.num_freq)).astype(np.float32)
     assert torch.equal(engine.griffin_lim_noalloc(lin, iters=3), engine.griffin_lim(lin, iters=3))
+
+
+def test_noalloc_griffin_lim_under_graph_capture(engine, hp):
+    """The use the entry point is for: the call is made while a stream is being captured into a hipGraph (nothing may
+    allocate, create streams or events, or synchronise there), the graph is replayed twice - the second time on new
+    input written into the same buffer - and each replay equals taco_griffin_lim on that input, bit for bit."""
+    import torch
+    from tacotron_amd import _lib
+    lib, h, dev = engine.lib, engine.handle, engine.device
+    rng = np.random.default_rng(32)
+    _, hop, win = hp.stft_params()
+    B, T, iters = 2, 200, 6
+    L = (T - 1) * hop + win
+    lin = torch.empty(B, T, hp.num_freq, device=dev)
+    got = torch.empty(B, L, device=dev)
+    want = torch.empty(B, L, device=dev)
+    ws = torch.empty(int(lib.taco_workspace_bytes(h, B, 1, -(-T // hp.outputs_per_step))), dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=side):
+        s = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = lib.taco_griffin_lim_noalloc(h, lin.data_ptr(), B, T, iters, got.data_ptr(), s)
+    assert rc == 0, _lib.last_error()
+    for rep in range(2):
+        lin.copy_(torch.from_numpy(rng.uniform(0.2, 1.0, size=(B, T, hp.num_freq)).astype(np.float32)))
+        got.fill_(float('nan'))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        s0 = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        assert lib.taco_griffin_lim(h, lin.data_ptr(), B, T, iters, want.data_ptr(), ws.data_ptr(), ws.numel(), s0) == 0
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(got).all()) and torch.equal(got, want), rep
