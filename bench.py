@@ -39,8 +39,21 @@ import time
 # The inherited value is kept when --keep-hw-queues is given; both are recorded on the JSON line, and at N=1 the
 # headline leg is repeated in a child process at the inherited setting (`value_at_inherited_hw_queues`).
 HWQ_INHERITED = os.environ.get('GPU_MAX_HW_QUEUES')
-if '--keep-hw-queues' not in sys.argv and int(HWQ_INHERITED or 0) < 8:
-    os.environ['GPU_MAX_HW_QUEUES'] = '8'
+
+
+def _argv_int(flag, default):
+    for i, a in enumerate(sys.argv):
+        if a == flag and i + 1 < len(sys.argv):
+            return int(sys.argv[i + 1])
+        if a.startswith(flag + '='):
+            return int(a.split('=', 1)[1])
+    return default
+
+
+# one hardware queue per stream in flight (at least 8, at most 32)
+HWQ_WANTED = max(8, min(32, _argv_int('--streams', 6)))
+if '--keep-hw-queues' not in sys.argv and int(HWQ_INHERITED or 0) < HWQ_WANTED:
+    os.environ['GPU_MAX_HW_QUEUES'] = str(HWQ_WANTED)
 
 import numpy as np
 
@@ -104,6 +117,7 @@ def family_work(hp, B, T_in, S):
         'decode_graph': ('hbm', (w_step + attn) * S),
         # roofline.achieved = (W_step + B*attn_bytes) * S / t_decode; one launch runs all S steps
         'dec_persistent': ('hbm', (w_step + attn) * S),
+        'dec_tile': ('hbm', (w_step + attn) * S),
         # scan: reads the hoisted input projections, writes the outputs, loads its recurrent weights once per WG
         'bigru_scan': ('hbm', rows * (6 * G + 2 * G) * 4 + 2 * B * 2 * (3 * G * G) * 4),
         'highway_combine': ('hbm', 4 * rows * (2 * 128 + 128 + 128) * 4),
@@ -183,7 +197,9 @@ def main():
     ap.add_argument('--streams', type=int, default=6,
                     help='independent batches in flight per GPU: step i runs on engine/stream i %% streams '
                          '(a serving loop keeps several batches in flight; 1 = strictly one batch at a time)')
-    ap.add_argument('--decode-mode', type=int, default=2, help='0 eager per-stage kernels, 1 hipGraph, 2 persistent kernel')
+    ap.add_argument('--decode-mode', type=int, default=2,
+                    help='0 eager per-stage kernels, 1 hipGraph, 2 persistent kernel (32 workgroups per 16 utterances: '
+                         'latency), 3 tile kernel (one workgroup per 16 utterances: throughput, wants --streams >= 12)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
@@ -306,7 +322,7 @@ def main():
         barrier()
         # decodes side by side: as many as fit the chip for mel + linear; one at a time when the vocoder's full-chip
         # launches of the other batches in flight run beside them (include/taco.h, taco_set_persist_budget)
-        budget = 32 * ((B + 15) // 16) if to_wav else 0
+        budget = 32 * ((B + 15) // 16) if to_wav and args.decode_mode == 2 else 0
         if os.environ.get('TACO_BENCH_DECODES'):             # (tuning) decodes allowed side by side, 0 = no limit
             budget = int(os.environ['TACO_BENCH_DECODES']) * 32 * ((B + 15) // 16)
         eng.set_persist_budget(budget)
@@ -329,7 +345,7 @@ def main():
     # HIP event pairs around every launch of the decode-loop kernel, on each engine's own stream, over the timed
     # region itself (two event records per batch): the roofline's launch duration is measured live, under the
     # same contention as `value`
-    loop_fam = {2: 'dec_persistent', 1: 'decode_graph'}.get(args.decode_mode)
+    loop_fam = {2: 'dec_persistent', 1: 'decode_graph', 3: 'dec_tile'}.get(args.decode_mode)
     if loop_fam and not args.no_roofline:
         for e in engines:
             e.timing_begin(loop_fam)
@@ -410,7 +426,9 @@ def main():
 
         # families of the decode mode that is NOT the one benchmarked would only run because asking for their
         # timing forces the per-stage path: leave them out
-        skip = {'dec_gemm', 'dec_attention', 'decode_graph'} if args.decode_mode == 2 else {'dec_persistent'}
+        skip = ({'dec_gemm', 'dec_attention', 'decode_graph', 'dec_tile'} if args.decode_mode == 2 else
+                {'dec_gemm', 'dec_attention', 'decode_graph', 'dec_persistent'} if args.decode_mode == 3 else
+                {'dec_persistent', 'dec_tile'})
         for k in kinds:
             if k not in skip and k != 'decode_graph':
                 one(k)
@@ -450,9 +468,9 @@ def main():
         res['rooflines'] = [dict(roof(k, fam[k]['ms'] * 1e-3 / fam[k]['launches'], fam[k]['launches']),
                                  traffic=tj.get(k, {}).get('bytes_per_launch'),
                                  measured='one batch alone, HIP event pair per launch')
-                            for k in ('conv_gemm', 'bigru_scan', 'dec_persistent', 'decode_graph', 'gl_iter')
+                            for k in ('conv_gemm', 'bigru_scan', 'dec_persistent', 'dec_tile', 'decode_graph', 'gl_iter')
                             if k in fam and k in work]
-        loop = 'dec_persistent' if 'dec_persistent' in fam else ('decode_graph' if 'decode_graph' in fam else None)
+        loop = next((k for k in ('dec_persistent', 'dec_tile', 'decode_graph') if k in fam), None)
         if loop:
             b, amt = work[loop]
             s2 = fam[loop]['ms'] * 1e-3

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'csrc', 'build')
 LIB = os.path.join(HERE, 'libtaco_hip.so')
-SOURCES = ['api.hip', 'gemm.hip', 'rnn.hip', 'decoder.hip', 'dec_persistent.hip', 'griffinlim.hip']
+SOURCES = ['api.hip', 'gemm.hip', 'rnn.hip', 'decoder.hip', 'dec_persistent.hip', 'dec_tile.hip', 'griffinlim.hip']
 HEADERS = ['kernels.h', 'fft_core.h', 'dec_common.h', os.path.join('..', '..', 'include', 'taco.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
@@ -39,7 +39,7 @@ def build(force=False, verbose=True):
             return o, True
         return o, False
 
-    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(7, len(SOURCES))) as ex:
         res = list(ex.map(compile_one, SOURCES))
     objs = [o for o, _ in res]
     if force or any(ch for _, ch in res) or not os.path.exists(LIB):

@@ -58,7 +58,7 @@ void Timing::end(int k, hipStream_t s) {
 
 static const char* kKernelNames[KK_COUNT] = {
     "conv_gemm", "highway_combine", "embed_gather", "bigru_scan", "dec_gemm", "dec_attention",
-    "dec_finalize", "decode_graph", "gl_mag", "gl_iter", "gl_ola", "dec_persistent"};
+    "dec_finalize", "decode_graph", "gl_mag", "gl_iter", "gl_ola", "dec_persistent", "dec_tile"};
 
 // ---------------------------------------------------------------------------------------
 // weights on the device
@@ -523,7 +523,11 @@ int run_cbhg(taco_ctx* c, const CbhgW& cb, const float* x, const int32_t* lens, 
         t.Wr = cb.rnn_in.W; t.br = cb.rnn_in.bias; t.ldwr = cb.rnn_in.ldw; t.Nr = cb.rnn_in.N;
         t.out = xp; t.ldo = 6 * cb.gru;
         launch_cbhg_tail(t, s, tm);
+#ifndef TACO_EXP_NO_BIGRU   // (timing experiment, wrong results: what the chip does with the scan's work gone)
         launch_bigru_scan(xp, cb.Pg, cb.Pc, lens, out, B, T, s, tm);
+#else
+        (void)hipMemsetAsync(out, 0, (size_t)M * 2 * cb.gru * sizeof(float), s);
+#endif
         return 0;
     }
     // highway layers (modules.py:87-88,100-123)
@@ -1053,6 +1057,37 @@ static int decode_impl(taco_ctx* c, const float* enc_out, int B, int T_in, int S
         return 0;
     }
 
+    // ---- mode 3: the whole loop as one launch, one workgroup per 16-utterance tile (dec_tile.hip): the throughput form
+    if (c->decode_mode == 3 && default_sizes && !keep && !teacher && !fine_timing && T_in <= 2048) {
+        keys_gemm(tm);
+        DecTileArgs a{};
+        auto stage = [&](int i, const DecW& w, int src0, int k0, int src1, int k1, int N, int epi, int out, int hh,
+                         int res, int res_out) {
+            a.st[i] = DecTileStage{w.Wp, w.bias, src0, k0 / 16, src1, k1 / 16, N, epi, out, hh, res, res_out};
+        };
+        const int P1 = hp.prenet_depth1, P2 = hp.prenet_depth2;
+        stage(0, c->pre1, DTB_GO, hp.num_mels, DTB_CTX, Dv, P1, DE_RELU, DTB_P1, -1, -1, -1);       // rnn_wrappers.py:25
+        stage(1, c->pre2, DTB_P1, P1, -1, 0, P2, DE_RELU, DTB_P2, -1, -1, -1);
+        stage(2, c->att_g, DTB_P2, P2, DTB_HATT, A, 2 * A, DE_GATES, DTB_RH, DTB_HATT, -1, -1);     // rnn_wrappers.py:26
+        stage(3, c->att_c, DTB_P2, P2, DTB_RH, A, A, DE_CAND, -1, DTB_HATT, -1, -1);
+        stage(4, c->query, DTB_HATT, A, -1, 0, A, DE_LINEAR, DTB_Q, -1, -1, -1);                    // decoder.py:20
+        stage(5, c->proj, DTB_HATT, A, DTB_CTX, Dv, D, DE_LINEAR, DTB_D0, -1, -1, -1);              // decoder.py:29
+        stage(6, c->g1_g, DTB_D0, D, DTB_H1, D, 2 * D, DE_GATES, DTB_RH, DTB_H1, -1, -1);           // decoder.py:30
+        stage(7, c->g1_c, DTB_D0, D, DTB_RH, D, D, DE_CAND, -1, DTB_H1, DTB_D0, DTB_O1);
+        stage(8, c->g2_g, DTB_O1, D, DTB_H2, D, 2 * D, DE_GATES, DTB_RH, DTB_H2, -1, -1);           // decoder.py:31
+        stage(9, c->g2_c, DTB_O1, D, DTB_RH, D, D, DE_CAND, -1, DTB_H2, DTB_O1, DTB_O2);
+        stage(10, c->outp, DTB_O2, D, -1, 0, NR, DE_OUT, -1, -1, -1, -1);                            // decoder.py:35
+        float* bufs[DTB_COUNT] = {d.go, d.ctx, d.hatt, d.h1, d.h2, d.p1, d.p2, d.rh, d.u, d.q, d.d0, d.o1, d.o2};
+        for (int i = 0; i < DTB_COUNT; ++i) a.buf[i] = bufs[i];
+        if (region_floats * 4 >= ((size_t)1 << 31)) return fail("taco_decode: decoder region larger than 2 GiB");
+        a.region = region; a.region_bytes = (unsigned)(region_floats * 4);
+        a.outQ = d.outQ; a.keys = d.keys; a.values = enc_out; a.attn_v = c->attn_v; a.alignS = d.alignS;
+        a.B = B; a.Bpad = Bp; a.T_in = T_in; a.S = S; a.NR = NR; a.M = hp.num_mels;
+        if (launch_dec_tile(a, s, tm)) return fail("taco_decode: cannot configure the tile decoder");
+        launch_dec_finalize(d.outQ, 0, d.alignS, d.nz, S, NR, B, Bp, T_in, mel, align, steps_run, s, tm);
+        return 0;
+    }
+
     // ---- modes 0/1: one kernel per stage; eager, or captured once per shape/buffer set and replayed
     float* teachQ = nullptr;
     if (teacher) {
@@ -1409,7 +1444,7 @@ extern "C" int32_t taco_get_persist_budget(int32_t device) {
 
 extern "C" int taco_set_decode_graph(taco_handle h, int32_t mode) {
     if (!h) return fail("taco_set_decode_graph: null handle");
-    if (mode < 0 || mode > 2) return fail("taco_set_decode_graph: mode must be 0, 1 or 2");
+    if (mode < 0 || mode > 3) return fail("taco_set_decode_graph: mode must be 0, 1, 2 or 3");
     if (mode == 2 && h->persist_broken) {
         // explicit re-arm after a timed-out persistent decode: wait for the handle's work, clear the sticky word
         HIP_OK(hipSetDevice(h->device));

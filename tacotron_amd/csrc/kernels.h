@@ -22,6 +22,7 @@ enum KernelKind : int {
     KK_GL_ITER,         // fused STFT -> phase -> iSTFT Griffin-Lim iteration
     KK_GL_OLA,          // final overlap-add
     KK_DEC_PERSIST,     // dec_persistent_kernel: the whole decode loop as one launch
+    KK_DEC_TILE,        // dec_tile_kernel: the whole decode loop as one launch, one workgroup per 16-utterance tile
     KK_COUNT
 };
 
@@ -130,6 +131,35 @@ void launch_dec_finalize(const float* outQ, int gran, const float* alignS, int32
                          bool stop_test = true);
 // targets [B, S*r, M] -> teachQ [S][M/4][Bpad][4]: frame (st+1)*r - 1 of every utterance, the input of step st+1
 void launch_dec_pack_teacher(const float* targets, float* teachQ, int S, int r, int M, int B, int Bpad, hipStream_t s);
+
+// Tile-resident decoder (dec_tile.hip): one workgroup per 16-utterance tile runs all S steps; the stages are those of
+// the per-stage path (api.hip decode_steps) as a table. Buffers are the Q-layout buffers of the per-stage path.
+enum DecTileBuf : int { DTB_GO = 0, DTB_CTX, DTB_HATT, DTB_H1, DTB_H2, DTB_P1, DTB_P2, DTB_RH, DTB_U, DTB_Q, DTB_D0,
+                        DTB_O1, DTB_O2, DTB_COUNT };
+constexpr int DT_STAGES = 11;        // pre1, pre2, attG, attC, query, proj, g1G, g1C, g2G, g2C, out
+constexpr int DT_QUERY_STAGE = 4;    // the attention follows this stage
+struct DecTileStage {
+    const float* Wp; const float* bias;   // packed [N/16][K/16][64][4]; bias [N] or null
+    int src0, k16_0, src1, k16_1;         // K segments: buffer ids (src1 = -1: none). Stage 0's src0 is the previous frame
+    int N, epi;                           // DecEpi
+    int out;                              // LINEAR / RELU: result; GATES: r*h; OUT: ignored (the step's slice of outQ)
+    int h;                                // GATES: reads h; CAND: reads + updates h in place
+    int res, res_out;                     // CAND: res_out = h_new + res, or -1
+};
+struct DecTileArgs {
+    DecTileStage st[DT_STAGES];
+    float* buf[DTB_COUNT];
+    float* region; unsigned region_bytes;   // the one allocation that holds every buffer above and outQ (K operands are
+                                            //   read through a buffer resource over it)
+    float* outQ;              // [S][NR/4][Bpad][4]
+    const float* keys;        // [B, T_in, 256]
+    const float* values;      // [B, T_in, 256]
+    const float* attn_v;      // [256]
+    float* alignS;            // [S][B][T_in]
+    int B, Bpad, T_in, S, NR, M;
+    int xcd0;                 // set by the launcher: XCD slot of tile 0 in this launch (placement only)
+};
+int launch_dec_tile(const DecTileArgs& a, hipStream_t s, Timing* tm);
 
 // Persistent decoder (dec_persistent.hip), default layer sizes only. Offsets o_* are in floats from `region`,
 // the contiguous, zero-filled block of granule buffers the workgroups exchange through (sc1 stores / loads):

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.EXPORTS) == names
-    assert lib.taco_num_kernel_kinds() == 12
+    assert lib.taco_num_kernel_kinds() == 13
     assert lib.taco_kernel_name(4) == b'dec_gemm'
 
 

@@ -119,6 +119,27 @@ def test_full_length_parity_cfg1(engine, hp, weights):
     assert np.all(same[decided])
 
 
+def test_full_length_parity_tile_decoder(engine, hp, weights):
+    """The same configuration through the throughput form of the decode loop (mode 3, one workgroup per 16-utterance
+    tile): all 200 feedback steps against the fp64 oracle, to the same bar."""
+    ids, lens = synth_ids(np.random.default_rng(0), 2, 150, ragged=False)
+    ref = O.tacotron_forward(ids, lens, weights, hp)
+    try:
+        engine.set_decode_graph(3)
+        o = engine.finish(engine.synthesize(ids, lens))
+    finally:
+        engine.set_decode_graph(2)
+    assert o['steps_run'] == 200
+    e_mel, e_lin = rel_l1(_np(o['mel']), ref['mel']), rel_l1(_np(o['linear']), ref['linear'])
+    al, al_r = _np(o['alignments']), ref['alignments']
+    top = np.sort(al_r, axis=1)
+    decided = (top[:, -1] - top[:, -2]) > 1e-6
+    same = al.argmax(1) == al_r.argmax(1)
+    print('cfg1 (mode 3): mel %.2e linear %.2e argmax same %d/%d decided %d' % (e_mel, e_lin, same.sum(), same.size, decided.sum()))
+    assert e_mel < 1e-3 and e_lin < 1e-3
+    assert np.all(same[decided])
+
+
 def test_ragged_batch_padding_semantics(engine, hp, weights):
     """A.6/A.8: pad id 0 embeds to a learned row, only the encoder BiGRU masks, attention runs over padded steps."""
     ids, lens = synth_ids(np.random.default_rng(9), 4, 60, ragged=True, min_len=20)

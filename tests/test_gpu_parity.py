@@ -178,6 +178,9 @@ def test_decode_modes_agree(engine, hp):
         engine.set_decode_graph(2)
         m3, a3, _ = engine.decode(enc, max_iters=7)
         m3b, a3b, _ = engine.decode(enc, max_iters=7)
+        engine.set_decode_graph(3)                       # one workgroup per 16-utterance tile (dec_tile.hip)
+        m4, a4, _ = engine.decode(enc, max_iters=7)
+        m4b, a4b, _ = engine.decode(enc, max_iters=7)
         torch.cuda.synchronize()
         engine.decode_status()
     finally:
@@ -185,11 +188,13 @@ def test_decode_modes_agree(engine, hp):
     assert torch.equal(m1, m2) and torch.equal(a1, a2) and torch.equal(m1, m1b)
     assert torch.equal(m3, m3b) and torch.equal(a3, a3b)
     assert rel_l1(_np(m3), _np(m1)) < 1e-5 and rel_l1(_np(a3), _np(a1)) < 1e-5
+    assert torch.equal(m4, m4b) and torch.equal(a4, a4b)
+    assert rel_l1(_np(m4), _np(m1)) < 1e-5 and rel_l1(_np(a4), _np(a1)) < 1e-5
 
 
-@pytest.mark.parametrize('mode', [1, 2])
+@pytest.mark.parametrize('mode', [1, 2, 3])
 def test_decode_parity_per_mode(engine, hp, weights, mode):
-    """Both decode implementations against the oracle (the other decode tests run the default, mode 2)."""
+    """Every decode implementation against the oracle (the other decode tests run the default, mode 2)."""
     rng = np.random.default_rng(77)
     enc = (0.5 * rng.standard_normal((18, 61, 256))).astype(np.float32).astype(np.float64)
     try:
@@ -204,7 +209,7 @@ def test_decode_batch_invariance(engine, hp):
     import torch
     rng = np.random.default_rng(4)
     enc = rng.standard_normal((19, 33, 256)).astype(np.float32)
-    for mode in (2, 1):
+    for mode in (2, 1, 3):
         try:
             engine.set_decode_graph(mode)
             m_all, a_all, _ = engine.decode(enc, max_iters=5)

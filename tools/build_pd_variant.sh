@@ -8,5 +8,5 @@ o=tacotron_amd/csrc/build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" \
     -c tacotron_amd/csrc/dec_persistent.hip -o $o/dec_persistent_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tacotron_amd/libtaco_v_$name.so \
-    $o/api.o $o/gemm.o $o/rnn.o $o/decoder.o $o/dec_persistent_$name.o $o/griffinlim.o
+    $o/api.o $o/gemm.o $o/rnn.o $o/decoder.o $o/dec_persistent_$name.o $o/dec_tile.o $o/griffinlim.o
 echo tacotron_amd/libtaco_v_$name.so

@@ -9,5 +9,5 @@ o=tacotron_amd/csrc/build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" \
     -c tacotron_amd/csrc/${GLSRC:-griffinlim.hip} -o $o/griffinlim_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tacotron_amd/libtaco_v_$name.so \
-    $o/api.o $o/gemm.o $o/rnn.o $o/decoder.o $o/dec_persistent.o $o/griffinlim_$name.o
+    $o/api.o $o/gemm.o $o/rnn.o $o/decoder.o $o/dec_persistent.o $o/dec_tile.o $o/griffinlim_$name.o
 echo tacotron_amd/libtaco_v_$name.so
