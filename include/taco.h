@@ -73,9 +73,10 @@ typedef struct TacoHParams {
     float   power;                /* 1.5 */
     int32_t max_iters;            /* 200 */
     int32_t griffin_lim_iters;    /* 60 */
-    /* max-pool of the CBHG (hparams.py:31-32,41-42 -> model/modules.py:70-71). The kernels implement the
-     * reference's values only (width 2, stride 1, fused into proj_1's operand loader); taco_create rejects
-     * anything else instead of silently computing a different graph. */
+    /* max-pool of the CBHG (hparams.py:31-32,41-42 -> model/modules.py:70-71): any window (the reference's 2 is
+     * fused into proj_1's operand loader, others run a kernel of their own), stride 1 only - another stride
+     * shortens the pooled sequence and the residual of modules.py:80 cannot be formed (the reference graph does
+     * not build either): taco_create refuses it instead of silently computing a different graph. */
     int32_t encoder_pooling_width;  /* 2 */
     int32_t encoder_pooling_stride; /* 1 */
     int32_t decoder_pooling_width;  /* 2 */

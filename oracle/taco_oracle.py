@@ -76,6 +76,20 @@ def maxpool2_same(x):
     return y
 
 
+def maxpool_same(x, width, stride=1):
+    """tf.layers.max_pooling1d(pool_size=width, strides=stride, padding='same') over time (modules.py:70-71): window
+    [t - (width-1)//2, t + width-1 - (width-1)//2] clipped to the sequence (the padding never wins the max). Only
+    stride 1 keeps the length the residual of modules.py:80 needs."""
+    if stride != 1:
+        raise ValueError('pooling stride %d: the CBHG residual (modules.py:80) needs stride 1' % stride)
+    T = x.shape[1]
+    pl = (width - 1) // 2
+    y = np.empty_like(x)
+    for t in range(T):
+        y[:, t] = x[:, max(t - pl, 0):min(t + width - 1 - pl, T - 1) + 1].max(axis=1)
+    return y
+
+
 def highwaynet(x, w, scope):
     """modules.py:100-123."""
     H = dense(x, w[scope + '/H/kernel'], w[scope + '/H/bias'], 'relu')
@@ -135,13 +149,13 @@ def prenet(x, w, scope, n_layers=2):
     return x
 
 
-def cbhg(x, lengths, w, scope, K, n_highway, highway_depth, gru_cells, stages=None):
+def cbhg(x, lengths, w, scope, K, n_highway, highway_depth, gru_cells, stages=None, pool_width=2, pool_stride=1):
     """modules.py:30-98. BN variables auto-number in the enclosing scope."""
     bank = np.concatenate(
         [convolute(x, w, '%s/conv_bank/conv_bank_%d' % (scope, k),
                    '%s/conv_bank/batch_normalization%s' % (scope, '' if k == 1 else '_%d' % (k - 1)), 'relu')
          for k in range(1, K + 1)], -1)                                            # :63-67
-    pooled = maxpool2_same(bank)                                                   # :70-71
+    pooled = maxpool2_same(bank) if (pool_width, pool_stride) == (2, 1) else maxpool_same(bank, pool_width, pool_stride)   # :70-71
     p1 = convolute(pooled, w, scope + '/proj_1', scope + '/batch_normalization', 'relu')   # :74-75
     p2 = convolute(p1, w, scope + '/proj_2', scope + '/batch_normalization_1', None)       # :76-77
     hw = p2 + x                                                                    # :80
@@ -175,7 +189,8 @@ def encode(ids, lengths, w, hp, stages=None):
     if stages is not None:
         stages['enc_prenet'] = pre
     return cbhg(pre, np.asarray(lengths), w, 'encoder_cbhg', hp.encoder_K, hp.encoder_num_highway_layers,
-                hp.encoder_highway_depth, hp.encoder_gru_num_cells, stages)
+                hp.encoder_highway_depth, hp.encoder_gru_num_cells, stages,
+                pool_width=hp.encoder_pooling_width, pool_stride=hp.encoder_pooling_stride)
 
 
 def decode(enc_out, w, hp, max_iters=None, return_scores=False, targets=None):
@@ -241,7 +256,8 @@ def decode(enc_out, w, hp, max_iters=None, return_scores=False, targets=None):
 def postnet(mel, w, hp, stages=None):
     """decoder.py:44-57: post-CBHG (K=8, no sequence lengths) + dense to num_freq."""
     post = cbhg(mel, None, w, 'post_cbhg', hp.decoder_K, hp.decoder_num_highway_layers,
-                hp.decoder_highway_depth, hp.decoder_gru_num_cells, stages)
+                hp.decoder_highway_depth, hp.decoder_gru_num_cells, stages,
+                pool_width=hp.decoder_pooling_width, pool_stride=hp.decoder_pooling_stride)
     return dense(post, w['dense/kernel'], w['dense/bias'])
 
 

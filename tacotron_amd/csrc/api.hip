@@ -73,6 +73,8 @@ struct DecW {
 };
 struct CbhgW {
     int in_depth = 0, K = 0, bank_filters = 0, proj1 = 0, proj2 = 0, highway_depth = 0, n_highway = 0, gru = 0;
+    int pool_width = 2;      // max-pool width (stride 1, 'same'): 2 is fused into proj_1's loader, 1 is the identity,
+                             //   wider windows run maxpool_same_kernel into a buffer of their own
     std::vector<ConvW> bank;
     GemmGroup* bank_groups = nullptr;   // device table: the K bank convolutions, widest first (one grouped launch)
     ConvW p1, p2, fix;
@@ -312,7 +314,17 @@ struct Loader {
             w.bias = upload(bias);
             if (!w.W || !w.bias) return false;
         }
-        {
+        if (G != BIGRU_H) {
+            // recurrent halves as they are (rows D .. D+G-1 of the TF kernels), k-major: bigru_scan_generic_kernel
+            std::vector<float> pg((size_t)2 * G * 2 * G), pc((size_t)2 * G * G);
+            for (int d = 0; d < 2; ++d) {
+                memcpy(&pg[(size_t)d * G * 2 * G], gk[d]->data + (size_t)D * 2 * G, (size_t)G * 2 * G * sizeof(float));
+                memcpy(&pc[(size_t)d * G * G], ck[d]->data + (size_t)D * G, (size_t)G * G * sizeof(float));
+            }
+            cb.Pg = upload(pg);
+            cb.Pc = upload(pc);
+            if (!cb.Pg || !cb.Pc) return false;
+        } else {
             // recurrent halves, one register image per thread of bigru_scan_kernel
             const int NT = BIGRU_THREADS, KG = 2 * G * G / NT, KC = G * G / NT;
             std::vector<float> pg((size_t)2 * KG * NT), pc((size_t)2 * KC * NT);
@@ -435,6 +447,7 @@ inline int bpad16(int B) { return (B + 15) / 16 * 16; }
 size_t cbhg_ws_bytes(const CbhgW& cb, size_t M) {
     size_t n = 0;
     n += al(M * cb.K * cb.bank_filters * 4);   // bank
+    if (cb.pool_width > 2) n += al(M * cb.K * cb.bank_filters * 4);   // pooled bank (windows wider than the fused 2)
     n += al(M * cb.proj1 * 4);                 // proj1
     n += al(M * cb.proj2 * 4);                 // proj2 + residual
     n += 2 * al(M * cb.highway_depth * 4);     // highway ping-pong
@@ -479,6 +492,7 @@ int run_cbhg(taco_ctx* c, const CbhgW& cb, const float* x, const int32_t* lens, 
     Timing* tm = c->timing_on ? &c->timing : nullptr;
     const int M = B * T;
     float* bank = ws.take<float>((size_t)M * cb.K * cb.bank_filters);
+    float* pooled = cb.pool_width > 2 ? ws.take<float>((size_t)M * cb.K * cb.bank_filters) : nullptr;
     float* p1 = ws.take<float>((size_t)M * cb.proj1);
     float* p2 = ws.take<float>((size_t)M * cb.proj2);
     float* hwA = ws.take<float>((size_t)M * cb.highway_depth);
@@ -498,9 +512,16 @@ int run_cbhg(taco_ctx* c, const CbhgW& cb, const float* x, const int32_t* lens, 
                      nullptr, 0, bank, ldb, ACT_RELU, 0, cb.bank_groups, cb.K, nullptr, 0};
         launch_conv_gemm(g, s, tm);
     }
-    // max-pool (modules.py:70-71) folded into proj_1's loader; proj_1 ReLU + BN (modules.py:74-75)
-    g = GemmArgs{bank, ldb, M, T, cb.p1.Cin, cb.p1.taps, cb.p1.padl, cb.p1.W, cb.p1.ldw, cb.p1.N, cb.p1.bias,
-                 cb.p1.scale, cb.p1.shift, nullptr, 0, p1, cb.proj1, ACT_RELU, 1, nullptr, 0, p1part, sk};
+    // max-pool (modules.py:70-71): the reference's width 2 is folded into proj_1's loader, width 1 is the identity,
+    // wider windows are materialised first; proj_1 ReLU + BN (modules.py:74-75)
+    const float* p1_in = bank;
+    if (cb.pool_width > 2) {
+        launch_maxpool_same(bank, pooled, M, T, ldb, cb.pool_width, s, tm);
+        p1_in = pooled;
+    }
+    g = GemmArgs{p1_in, ldb, M, T, cb.p1.Cin, cb.p1.taps, cb.p1.padl, cb.p1.W, cb.p1.ldw, cb.p1.N, cb.p1.bias,
+                 cb.p1.scale, cb.p1.shift, nullptr, 0, p1, cb.proj1, ACT_RELU, cb.pool_width == 2 ? 1 : 0, nullptr, 0,
+                 p1part, sk};
     launch_conv_gemm(g, s, tm);
     // proj_2 linear + BN, + residual (modules.py:76-80)
     g = GemmArgs{p1, cb.proj1, M, T, cb.p2.Cin, cb.p2.taps, cb.p2.padl, cb.p2.W, cb.p2.ldw, cb.p2.N, cb.p2.bias,
@@ -524,7 +545,7 @@ int run_cbhg(taco_ctx* c, const CbhgW& cb, const float* x, const int32_t* lens, 
         t.out = xp; t.ldo = 6 * cb.gru;
         launch_cbhg_tail(t, s, tm);
 #ifndef TACO_EXP_NO_BIGRU   // (timing experiment, wrong results: what the chip does with the scan's work gone)
-        launch_bigru_scan(xp, cb.Pg, cb.Pc, lens, out, B, T, s, tm);
+        launch_bigru_scan(xp, cb.Pg, cb.Pc, lens, out, B, T, cb.gru, s, tm);
 #else
         (void)hipMemsetAsync(out, 0, (size_t)M * 2 * cb.gru * sizeof(float), s);
 #endif
@@ -544,7 +565,7 @@ int run_cbhg(taco_ctx* c, const CbhgW& cb, const float* x, const int32_t* lens, 
     g = GemmArgs{h, cb.highway_depth, M, T, cb.rnn_in.Cin, 1, 0, cb.rnn_in.W, cb.rnn_in.ldw, cb.rnn_in.N,
                  cb.rnn_in.bias, nullptr, nullptr, nullptr, 0, xp, 6 * cb.gru, ACT_NONE, 0};
     launch_conv_gemm(g, s, tm);
-    launch_bigru_scan(xp, cb.Pg, cb.Pc, lens, out, B, T, s, tm);
+    launch_bigru_scan(xp, cb.Pg, cb.Pc, lens, out, B, T, cb.gru, s, tm);
     return 0;
 }
 
@@ -582,18 +603,22 @@ extern "C" int taco_create(const TacoHParams* hp, const TacoWeightEntry* weights
         return fail("taco_create: every layer width must be a positive multiple of 16");
     if (p.encoder_highway_depth % 32 || p.decoder_highway_depth % 32)
         return fail("taco_create: highway depths must be multiples of 32 (fused highway epilogue)");
-    if (p.encoder_gru_cells != BIGRU_H || p.decoder_gru_cells != BIGRU_H)
-        return fail("taco_create: the BiGRU scan kernel is built for %d cells per direction", BIGRU_H);
+    if (!m16(p.encoder_gru_cells) || !m16(p.decoder_gru_cells) || p.encoder_gru_cells > 2048 || p.decoder_gru_cells > 2048)
+        return fail("taco_create: *_gru_num_cells must be a positive multiple of 16 (at most 2048)");
     if (p.encoder_proj2 != p.prenet_depth2 || p.decoder_proj2 != p.num_mels)
         return fail("taco_create: the CBHG residual needs proj_num_filters[1] == input depth (modules.py:80)");
     if (p.n_fft != 2048 || p.num_freq != 1025 || p.win_length > 2048 || p.win_length < 2 || (p.win_length & 1) ||
         (p.hop_length & 1) || p.hop_length < 2 || p.hop_length > p.win_length)
         return fail("taco_create: Griffin-Lim kernel needs n_fft=2048, num_freq=1025, even hop <= even win <= 2048");
-    if (p.encoder_pooling_width != 2 || p.encoder_pooling_stride != 1 || p.decoder_pooling_width != 2 ||
-        p.decoder_pooling_stride != 1)
-        return fail("taco_create: only the reference's max-pool (pooling_width 2, pooling_stride 1; hparams.py:31-32,"
-                    "41-42) is implemented, got encoder %d/%d decoder %d/%d", p.encoder_pooling_width,
-                    p.encoder_pooling_stride, p.decoder_pooling_width, p.decoder_pooling_stride);
+    // max-pool (hparams.py:31-32,41-42 -> modules.py:70-71): any window, stride 1 only - with another stride the
+    // pooled sequence is shorter than the CBHG's input and the residual of modules.py:80 cannot be formed (the
+    // reference graph does not build either)
+    if (p.encoder_pooling_stride != 1 || p.decoder_pooling_stride != 1 || p.encoder_pooling_width < 1 ||
+        p.decoder_pooling_width < 1 || p.encoder_pooling_width > 64 || p.decoder_pooling_width > 64)
+        return fail("taco_create: max-pool needs pooling_stride 1 (the residual of modules.py:80 adds the CBHG input to a "
+                    "sequence of the same length) and 1 <= pooling_width <= 64, got encoder %d/%d decoder %d/%d",
+                    p.encoder_pooling_width, p.encoder_pooling_stride, p.decoder_pooling_width,
+                    p.decoder_pooling_stride);
     if (p.encoder_K < 1 || p.decoder_K < 1 || p.outputs_per_step < 1 || p.num_chars < 1 || p.encoder_highways < 0 ||
         p.decoder_highways < 0)
         return fail("taco_create: bad hparams");
@@ -639,6 +664,7 @@ extern "C" int taco_create(const TacoHParams* hp, const TacoWeightEntry* weights
     c->enc.in_depth = p.prenet_depth2; c->enc.K = p.encoder_K; c->enc.bank_filters = p.encoder_bank_filters;
     c->enc.proj1 = p.encoder_proj1; c->enc.proj2 = p.encoder_proj2; c->enc.highway_depth = p.encoder_highway_depth;
     c->enc.n_highway = p.encoder_highways; c->enc.gru = p.encoder_gru_cells;
+    c->enc.pool_width = p.encoder_pooling_width; c->post.pool_width = p.decoder_pooling_width;
     c->post.in_depth = p.num_mels; c->post.K = p.decoder_K; c->post.bank_filters = p.decoder_bank_filters;
     c->post.proj1 = p.decoder_proj1; c->post.proj2 = p.decoder_proj2; c->post.highway_depth = p.decoder_highway_depth;
     c->post.n_highway = p.decoder_highways; c->post.gru = p.decoder_gru_cells;

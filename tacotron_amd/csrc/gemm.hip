@@ -557,4 +557,32 @@ void launch_embed_gather(const int32_t* ids, const float* lut, float* out, int M
     if (tm) tm->end(KK_GATHER, s);
 }
 
+// Max-pool over time, stride 1, 'same' padding, any window (the reference's width 2 never comes here: it is folded into
+// proj_1's operand loader). One thread per four channels of a row; the padding does not take part in the max.
+__global__ void maxpool_same_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int T, int ld4,
+                                    int width) {
+    const long total = (long)M * ld4;
+    const int pl = (width - 1) / 2, pr = width - 1 - pl;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / ld4), c4 = (int)(i - (long)m * ld4);
+        const int t = m % T;
+        const int lo = max(t - pl, 0), hi = min(t + pr, T - 1);
+        const float4* row = reinterpret_cast<const float4*>(x) + (long)(m - t) * ld4 + c4;
+        float4 v = row[(long)lo * ld4];
+        for (int u = lo + 1; u <= hi; ++u) {
+            const float4 w = row[(long)u * ld4];
+            v.x = fmaxf(v.x, w.x); v.y = fmaxf(v.y, w.y); v.z = fmaxf(v.z, w.z); v.w = fmaxf(v.w, w.w);
+        }
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+
+void launch_maxpool_same(const float* x, float* out, int M, int T, int ld, int width, hipStream_t s, Timing* tm) {
+    if (tm) tm->begin(KK_CONV_GEMM, s);
+    const long total = (long)M * (ld / 4);
+    const int blocks = (int)std::max<long>(1, std::min<long>(8192, (total + 255) / 256));
+    hipLaunchKernelGGL(maxpool_same_kernel, dim3(blocks), dim3(256), 0, s, x, out, M, T, ld / 4, width);
+    if (tm) tm->end(KK_CONV_GEMM, s);
+}
+
 }  // namespace taco

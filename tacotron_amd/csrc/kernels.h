@@ -83,16 +83,21 @@ struct CbhgTailArgs {
 void launch_cbhg_tail(const CbhgTailArgs& a, hipStream_t s, Timing* tm);
 void launch_conv_gemm(const GemmArgs& a, hipStream_t s, Timing* tm);
 
+// tf.layers.max_pooling1d(pool_size = width, strides = 1, padding = 'same') over time on [M = B*T, ld] rows
+// (model/modules.py:70-71): out[t] = max(x[t - (width-1)/2 .. t + width-1 - (width-1)/2]) within the utterance.
+void launch_maxpool_same(const float* x, float* out, int M, int T, int ld, int width, hipStream_t s, Timing* tm);
+
 // out[m, :] = lut[clamp(ids[m]), :]  (width floats, multiple of 4)
 void launch_embed_gather(const int32_t* ids, const float* lut, float* out, int M, int width, int num_rows,
                          hipStream_t s, Timing* tm);
 
-// Bidirectional GRU(128) scan. xp [B*T, 768] = x @ [fw gates|fw cand|bw gates|bw cand] + biases,
-// Pg/Pc the packed recurrent weights per direction; lens may be null. out [B*T, 256].
+// Bidirectional GRU(G) scan. xp [B*T, 6G] = x @ [fw gates|fw cand|bw gates|bw cand] + biases; lens may be null;
+// out [B*T, 2G]. G = 128 (the reference's value): Pg/Pc are the register images of bigru_scan_kernel per direction;
+// any other G: Pg [2][G][2G], Pc [2][G][G], the recurrent halves k-major (bigru_scan_generic_kernel).
 constexpr int BIGRU_H = 128;
 constexpr int BIGRU_THREADS = 512;
 void launch_bigru_scan(const float* xp, const float* Pg, const float* Pc, const int32_t* lens, float* out,
-                       int B, int T, hipStream_t s, Timing* tm);
+                       int B, int T, int G, hipStream_t s, Timing* tm);
 
 // Decoder-step skinny GEMM on "Q layout" activations: a vector of dimension K for batch column b
 // lives at act[(k/4)*Bpad + b] as float4 {k..k+3}; Bpad is a multiple of 16.

@@ -150,10 +150,72 @@ __global__ __launch_bounds__(BIGRU_THREADS) void bigru_scan_kernel(
 #undef BIGRU_LOAD_CHUNK
 }
 
+// The same recurrence for any number of cells G (hparams *_gru_num_cells other than the reference's 128): one
+// 256-thread workgroup per (utterance, direction); the recurrent weights do not fit a register image in general, so
+// they are read from L2 every step, k-major ([G][2G] gates, [G][G] candidate: coalesced over the outputs); state,
+// r*h and u in LDS. Functional reach, not a tuned path: ~G/8 us per step.
+constexpr int BIGRU_GEN_THREADS = 256;
+__global__ __launch_bounds__(BIGRU_GEN_THREADS) void bigru_scan_generic_kernel(
+    const float* __restrict__ xp, const float* __restrict__ Wg, const float* __restrict__ Wc,
+    const int32_t* __restrict__ lens, float* __restrict__ out, int T, int G) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    float* hs = gsm;                // [2][G]
+    float* rh = gsm + 2 * G;        // [G]
+    float* us = rh + G;             // [G]
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    int len = lens ? lens[b] : T;
+    len = len < 0 ? 0 : (len > T ? T : len);
+    const float* wg = Wg + (size_t)dir * G * 2 * G;
+    const float* wc = Wc + (size_t)dir * G * G;
+    const float* xrow = xp + (size_t)b * T * (6 * G) + dir * 3 * G;
+    float* orow = out + (size_t)b * T * (2 * G) + dir * G;
+    for (int i = tid; i < 2 * G; i += BIGRU_GEN_THREADS) hs[i] = 0.f;
+    for (int i = tid; i < (T - len) * G; i += BIGRU_GEN_THREADS) orow[(size_t)(len + i / G) * 2 * G + (i % G)] = 0.f;
+    __syncthreads();
+    for (int s = 0; s < len; ++s) {
+        const int t = dir == 0 ? s : len - 1 - s;
+        const float* h = hs + (s & 1) * G;
+        float* hn_s = hs + ((s & 1) ^ 1) * G;
+        const float* xr = xrow + (size_t)t * 6 * G;
+        for (int o = tid; o < 2 * G; o += BIGRU_GEN_THREADS) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int k = 0; k < G; k += 4) {
+                a0 = fmaf(h[k], wg[(size_t)k * 2 * G + o], a0);
+                a1 = fmaf(h[k + 1], wg[(size_t)(k + 1) * 2 * G + o], a1);
+                a2 = fmaf(h[k + 2], wg[(size_t)(k + 2) * 2 * G + o], a2);
+                a3 = fmaf(h[k + 3], wg[(size_t)(k + 3) * 2 * G + o], a3);
+            }
+            const float g = sigmoidf_(((a0 + a1) + (a2 + a3)) + xr[o]);
+            if (o < G) rh[o] = g * h[o];
+            else us[o - G] = g;
+        }
+        __syncthreads();
+        for (int o = tid; o < G; o += BIGRU_GEN_THREADS) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int k = 0; k < G; k += 4) {
+                a0 = fmaf(rh[k], wc[(size_t)k * G + o], a0);
+                a1 = fmaf(rh[k + 1], wc[(size_t)(k + 1) * G + o], a1);
+                a2 = fmaf(rh[k + 2], wc[(size_t)(k + 2) * G + o], a2);
+                a3 = fmaf(rh[k + 3], wc[(size_t)(k + 3) * G + o], a3);
+            }
+            const float c = tanhf_(((a0 + a1) + (a2 + a3)) + xr[2 * G + o]);
+            const float uu = us[o];
+            const float hn = uu * h[o] + (1.f - uu) * c;
+            hn_s[o] = hn;
+            orow[(size_t)t * 2 * G + o] = hn;
+        }
+        __syncthreads();
+    }
+}
+
 void launch_bigru_scan(const float* xp, const float* Pg, const float* Pc, const int32_t* lens, float* out,
-                       int B, int T, hipStream_t s, Timing* tm) {
+                       int B, int T, int G, hipStream_t s, Timing* tm) {
     if (tm) tm->begin(KK_BIGRU, s);
-    hipLaunchKernelGGL(bigru_scan_kernel, dim3(B, 2), dim3(BIGRU_THREADS), 0, s, xp, Pg, Pc, lens, out, T);
+    if (G == BIGRU_H)
+        hipLaunchKernelGGL(bigru_scan_kernel, dim3(B, 2), dim3(BIGRU_THREADS), 0, s, xp, Pg, Pc, lens, out, T);
+    else
+        hipLaunchKernelGGL(bigru_scan_generic_kernel, dim3(B, 2), dim3(BIGRU_GEN_THREADS), (size_t)4 * G * sizeof(float),
+                           s, xp, Pg, Pc, lens, out, T, G);
     if (tm) tm->end(KK_BIGRU, s);
 }
 

@@ -77,17 +77,18 @@ def test_create_rejects_wrong_struct_size():
         assert 'struct_size' in _lib.last_error() and not h.value
 
 
-def test_create_rejects_non_default_pooling():
-    """hparams.py:31-32,41-42 -> modules.py:70-71: only pooling width 2 / stride 1 is implemented (fused into proj_1's
-    operand loader); any other value is refused at taco_create (before any device call) instead of silently computing
-    a different graph."""
+def test_create_rejects_pooling_stride():
+    """hparams.py:31,41 -> modules.py:70-71,80: any pooling window runs, but a stride other than 1 shortens the pooled
+    sequence, so the residual `proj2 + inputs` cannot be formed (the reference graph does not build either): refused at
+    taco_create (before any device call) instead of silently computing a different graph."""
     import ctypes
     from tacotron_amd import _lib
     from tacotron_amd.hparams import HParams
     lib = _lib.load_library()
-    for name in ('encoder_pooling_width', 'encoder_pooling_stride', 'decoder_pooling_width', 'decoder_pooling_stride'):
+    for name, val in (('encoder_pooling_stride', 2), ('decoder_pooling_stride', 3), ('encoder_pooling_width', 0),
+                      ('decoder_pooling_width', 65)):
         hp = HParams()
-        hp.set_hparam(name, 3)
+        hp.set_hparam(name, val)
         s = _lib.make_hparams_struct(hp)
         entries = (_lib.TacoWeightEntry * 1)()
         h = ctypes.c_void_p()

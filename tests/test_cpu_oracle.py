@@ -4,6 +4,7 @@ import os
 import subprocess
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import taco_oracle as O
@@ -44,6 +45,14 @@ def test_maxpool_and_batchnorm_vs_torch():
     xt = torch.nn.functional.pad(torch.from_numpy(x).permute(0, 2, 1), (0, 1), value=-np.inf)
     ref = torch.nn.functional.max_pool1d(xt, 2, 1).permute(0, 2, 1).numpy()
     assert np.array_equal(O.maxpool2_same(x), ref)
+    # any window at stride 1 (hparams *_pooling_width): TF 'same' pads (w-1)//2 on the left, the rest on the right
+    for width in (1, 2, 3, 4, 5, 9, 12):
+        pl = (width - 1) // 2
+        xt = torch.nn.functional.pad(torch.from_numpy(x).permute(0, 2, 1), (pl, width - 1 - pl), value=-np.inf)
+        ref = torch.nn.functional.max_pool1d(xt, width, 1).permute(0, 2, 1).numpy()
+        assert np.array_equal(O.maxpool_same(x, width), ref), width
+    with pytest.raises(ValueError):
+        O.maxpool_same(x, 2, stride=2)
     g, b, m, v = (rng.uniform(0.5, 1.5, 4) for _ in range(4))
     ref = torch.nn.functional.batch_norm(torch.from_numpy(x).reshape(-1, 4), torch.from_numpy(m), torch.from_numpy(v),
                                          torch.from_numpy(g), torch.from_numpy(b), False, 0.0, 1e-3)

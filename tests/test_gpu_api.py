@@ -392,6 +392,12 @@ def test_c_abi_error_paths(engine, hp, weights):
     dict(prenet_depths=[128, 64], attention_depth=128, decoder_depth=128, postnet_depth=128, embedded_depth=128,
          encoder_bank_num_filters=64, decoder_bank_num_filters=96, encoder_proj_num_filters=[96, 64],
          decoder_proj_num_filters=[128, 80], encoder_highway_depth=64, decoder_highway_depth=96, outputs_per_step=2),
+    # max-pool windows other than the reference's 2 (hparams.py:32,42): 1 = identity, wider = a kernel of its own
+    dict(encoder_pooling_width=1, decoder_pooling_width=3),
+    dict(encoder_pooling_width=4, decoder_pooling_width=5, encoder_K=6, decoder_K=3),
+    # BiGRU cell counts other than 128 (hparams.py:37,47): the generic scan; the encoder's also sets the memory depth
+    dict(encoder_gru_num_cells=64, decoder_gru_num_cells=96),
+    dict(encoder_gru_num_cells=160, decoder_gru_num_cells=32, outputs_per_step=4),
 ])
 def test_non_default_hparams(overrides):
     """The reference's layer sizes are hparams (`--hparams k=v`): a model with other sizes runs through the general
