@@ -404,6 +404,10 @@ def main():
                 'batch_mel_linear': lat_ms if not args.to_wav else p50_latency(eng, ids, lens, False, out, 5),
                 'batch_to_wav': lat_ms if args.to_wav else p50_latency(eng, ids, lens, True, out, 5),
                 'batch': B}
+            # a batch that has the GPU to itself: its vocoder as two utterance groups on two streams (taco_set_gl_split)
+            eng.set_gl_split(2)
+            res['latency']['batch_to_wav_gl_split2'] = p50_latency(eng, ids, lens, True, out, 5)
+            eng.set_gl_split(1)
             # BASELINE.json configs[4]: B=1 with the per-stage step chain captured into a hipGraph (decode mode 1)
             eng.set_decode_graph(1)
             res['latency']['b1_hipgraph_mel_linear'] = p50_latency(eng, ids[:1], lens[:1], False, o1, 9)

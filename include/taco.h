@@ -217,6 +217,14 @@ int taco_set_persist_budget(int32_t device, int32_t workgroups);
  * changes it for a job reads it first and puts it back afterwards (tacotron_amd/pipeline.py does). */
 int32_t taco_get_persist_budget(int32_t device);
 
+/* Scheduling knob of taco_griffin_lim / taco_synthesize (no reference counterpart): run the utterances of a batch as
+ * `groups` (1..4, at least 8 utterances each) independent chains on streams of the handle's own, forked from and joined
+ * to the caller's stream, so that the tail of one group's full-chip launch is filled by another group's. Same kernels
+ * per utterance, same bits. Worth it for a batch that has the GPU to itself (B = 32: 6.2 -> 5.7 ms per 60 iterations);
+ * with several batches in flight the tails are filled by the other batches anyway and the extra streams cost
+ * throughput: default 1. Ignored under stream capture and while launches are being timed. */
+int taco_set_gl_split(taco_handle h, int32_t groups);
+
 /* Synchronous check of the last persistent decode (reads a few device words; call after the stream has been
  * synchronised): <0 if one of its bounded inter-workgroup waits timed out, in which case its outputs are invalid.
  * Failure handling of the persistent mode (no reference counterpart; the reference's loop is a tf.while_loop inside

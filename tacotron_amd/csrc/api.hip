@@ -122,6 +122,7 @@ struct taco_ctx {
     // Griffin-Lim of a batch as up to 4 utterance groups on streams of their own (gl_impl): created lazily, on first use
     hipStream_t gl_streams[3] = {nullptr, nullptr, nullptr};
     hipEvent_t gl_fork = nullptr, gl_join[3] = {nullptr, nullptr, nullptr};
+    int gl_split = 1;              // taco_set_gl_split: utterance groups of a Griffin-Lim call on streams of their own
     bool status_pending = false;
     bool persist_broken = false;
     unsigned long long* dbg_stamps = nullptr;  // PD_STAMPS builds: 64 s_memrealtime stamps of one step
@@ -1242,10 +1243,12 @@ static int gl_impl(taco_ctx* c, const float* linear, int B, int T, int iters, fl
     // round. Utterances do not depend on each other, so a large batch runs as G groups of utterances, each a chain of
     // its own on a stream of its own: the tail of one group's launch is filled by the other groups' launches.
     // (Not when the caller captures `s` or when launches are being timed on `s`.)
-    static const int split_env = getenv("TACO_GL_SPLIT") ? atoi(getenv("TACO_GL_SPLIT")) : 1;
+    // (taco_set_gl_split: worth it for a batch that has the GPU to itself, 6.2 -> 5.7 ms at B = 32; with several
+    // batches in flight the tails fill with the other batches' work anyway and the extra streams cost more: default 1)
+    static const int split_env = getenv("TACO_GL_SPLIT") ? atoi(getenv("TACO_GL_SPLIT")) : 0;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = s != nullptr && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-    int G = std::min(std::min(split_env, 4), B / 8);
+    int G = std::min(std::min(split_env > 0 ? split_env : c->gl_split, 4), B / 8);
     if (capturing || tm || s == nullptr) G = 1;
     if (G > 1) {
         for (int g = 0; g < G - 1 && G > 1; ++g) {
@@ -1459,6 +1462,13 @@ extern "C" int taco_set_persist_budget(int32_t device, int32_t workgroups) {
     if (device < 0 || workgroups < 0) return fail("taco_set_persist_budget: negative argument");
     std::lock_guard<std::mutex> lk(g_persist_mu);
     g_persist_budget[device] = workgroups;
+    return 0;
+}
+
+extern "C" int taco_set_gl_split(taco_handle h, int32_t groups) {
+    if (!h) return fail("taco_set_gl_split: null handle");
+    if (groups < 1 || groups > 4) return fail("taco_set_gl_split: groups must be 1..4");
+    h->gl_split = groups;
     return 0;
 }
 

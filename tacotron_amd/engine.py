@@ -124,6 +124,11 @@ class TacoEngine:
         other batches run beside the decodes."""
         self._check(self.lib.taco_set_persist_budget(int(self.device.index or 0), int(workgroups)))
 
+    def set_gl_split(self, groups):
+        """Griffin-Lim of a batch as 1..4 utterance groups on streams of the handle's own (include/taco.h): 2 is the
+        better setting for a batch that has the GPU to itself, 1 (default) with several batches in flight."""
+        self._check(self.lib.taco_set_gl_split(self.handle, int(groups)))
+
     def get_persist_budget(self):
         return int(self.lib.taco_get_persist_budget(int(self.device.index or 0)))
 

@@ -445,6 +445,25 @@ def test_griffin_lim_batch_and_run_invariance(engine, hp):
     assert np.array_equal(_np(engine.griffin_lim_librosa(lin[5:6], u[5:6], iters=2))[0], full[5])
 
 
+def test_griffin_lim_group_split_is_bit_identical(engine, hp):
+    """taco_set_gl_split: the utterances of a batch as 2..4 chains on streams of the handle's own (a scheduling choice
+    for a batch that has the GPU to itself): the same bits as the single chain, for uneven group sizes too."""
+    import torch
+    rng = np.random.default_rng(41)
+    lin = rng.uniform(0.2, 1.0, size=(27, 70, hp.num_freq)).astype(np.float32)
+    ref = engine.griffin_lim(lin, iters=4)
+    try:
+        for groups in (2, 3, 4):
+            engine.set_gl_split(groups)
+            got = engine.griffin_lim(lin, iters=4)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref), groups
+    finally:
+        engine.set_gl_split(1)
+    with pytest.raises(Exception):
+        engine.set_gl_split(5)
+
+
 def test_hip_path_matches_committed_goldens():
     """The HIP path against tests/golden/oracle_small.npz read from disk (no oracle call at run time): the same vectors
     the CPU suite pins the oracle with (tests/test_cpu_oracle.py::test_oracle_matches_golden_vectors)."""
