@@ -14,6 +14,7 @@ __global__ void k(float* out, unsigned long long* cyc) {
     const f2 xv = {x, x + 1.f};
 #pragma unroll
     for (int i = 0; i < CH; ++i) { a[i] = f2{(float)i, (float)(i + 1)} + xv; s[i] = (float)i + x; }
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
@@ -27,11 +28,12 @@ __global__ void k(float* out, unsigned long long* cyc) {
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     float r = 0.f;
 #pragma unroll
     for (int i = 0; i < CH; ++i) r += a[i].x + a[i].y + s[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
-    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; cyc[256 + blockIdx.x] = r1 - r0; }
 }
 
 template <int KIND>
@@ -48,21 +50,22 @@ void run(const char* name, float* out, unsigned long long* cyc) {
         hipDeviceSynchronize();
         float ms = 0;
         hipEventElapsedTime(&ms, e0, e1);
-        unsigned long long h[256];
+        unsigned long long h[512];
         hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
-        double avg = 0;
-        for (int i = 0; i < 256; ++i) avg += (double)h[i];
-        avg /= 256;
+        double avg = 0, rt = 0;
+        for (int i = 0; i < 256; ++i) { avg += (double)h[i]; rt += (double)h[256 + i]; }
+        avg /= 256; rt /= 256;
         // memtime ticks per wave-instruction issued on one SIMD: wps waves each issue ITERS*CH instructions
-        printf("%-22s waves/SIMD %d: %.2f ticks per instruction per SIMD (%.3f ms, %.0f ticks/wave)\n", name, wps,
-               avg / ((double)ITERS * CH * wps), ms, avg);
+        // s_memrealtime: constant 100 MHz; the loop's wall time per wave = rt * 10 ns
+        printf("%-22s waves/SIMD %d: %.2f memtime ticks per instruction per SIMD (%.3f ms launch, %.0f ticks/wave, loop %.1f us by the 100 MHz clock = %.2f ns per instruction per SIMD)\n",
+               name, wps, avg / ((double)ITERS * CH * wps), ms, avg, rt * 0.01, rt * 10.0 / ((double)ITERS * CH * wps));
     }
 }
 
 int main() {
     float* out; unsigned long long* cyc;
     hipMalloc(&out, 256 * 1024 * sizeof(float)); hipMemset(out, 0, 256 * 1024 * sizeof(float));
-    hipMalloc(&cyc, 256 * sizeof(unsigned long long));
+    hipMalloc(&cyc, 512 * sizeof(unsigned long long));
     run<0>("v_add_f32", out, cyc);
     run<1>("v_fma_f32", out, cyc);
     run<2>("v_pk_add_f32", out, cyc);

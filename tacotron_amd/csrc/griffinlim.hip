@@ -423,8 +423,11 @@ __device__ __forceinline__ void gl_lds_barrier() { asm volatile("s_waitcnt lgkmc
 // the own sum, and b, c, d = own / next run's raw head frames in ascending order or 0: the very additions of the
 // frame-state gather, in the same order, so both states give the same bits (and so do runs of 8 and of 16 frames).
 // (1.3 KB per frame written, 2.3 KB read at run = 16.)
+#ifndef GL_EXP_LB      // (experiment: minimum waves per SIMD the register allocation is held to)
+#define GL_EXP_LB 2
+#endif
 template <int WIN, int HOP, bool SIN, bool SOUT>
-__global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __restrict__ frames_in,
+__global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const float* __restrict__ frames_in,
                                                                 const float* __restrict__ mag,
                                                                 float* __restrict__ frames_out,
                                                                 const float* __restrict__ lds_image, int B, int T,
@@ -948,6 +951,17 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
             GL_STAMP(sb);
             a1(A, Bf);
             if constexpr (SOUT) gl_lds_barrier();           // (B1) every input of the round is in registers
+#ifdef GL_EXP_SINGLE   // (experiment: the two frames one after the other, no interleave: what one frame costs a wave)
+            const int fn = fi + 2 * GL_WAVES;
+            d1(A); x_pass1(A); m2f(A); dft16<false>(A.v); x_pass2(A); m3(A, mkA, mnA, m512A); x3(A);
+            if (fn < nfr) load_mag(mkA, mnA, m512A, fn);
+            m2i(A); x4(A);
+            if constexpr (SOUT) m7s(A, fi, 0, true, true); else m7(A, true);
+            d1(Bf); x_pass1(Bf); m2f(Bf); dft16<false>(Bf.v); x_pass2(Bf); m3(Bf, mkB, mnB, m512B); x3(Bf);
+            if (fn < nfr) load_mag(mkB, mnB, m512B, min(fn + GL_WAVES, nfr - 1));
+            m2i(Bf); x4(Bf);
+            if constexpr (SOUT) m7s(Bf, fi + GL_WAVES, 1, pair, false); else m7(Bf, pair);
+#else
             d1(A);   x_pass1(A);
             d1(Bf);  GL2_LAND(A.v);  x_pass1(Bf);
             GL_STAMP(sb + 1);
@@ -976,6 +990,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter2_kernel(const float* __
                 GL2_LAND(Bf.v);
                 m7(Bf, pair);
             }
+#endif
             GL_STAMP(sb + 7);
         }
         if constexpr (SOUT) {
