@@ -14,6 +14,7 @@
 // exchange data through its private, padded LDS buffer.
 // HBM/L2 traffic per frame and iteration: 4.1 KB magnitudes + ~5.7 KB frame reads + 4.8 KB frame writes.
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 #include "fft_core.h"
@@ -455,8 +456,8 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
     // SOUT: partial sums of the samples [8 HOP, 8 HOP + HEAD) of the run, which frames of both rounds of a 16-frame run
     // cover (the second round's inputs still sit in yseg at those places when the first round's outputs arrive)
     float* side_s = reinterpret_cast<float*>(fft_s + GL_WAVES * GL2_LDS);
-    float* zero_s = side_s + WIN - HOP;                  // SOUT: four zeros (set before the first barrier)
-    if (SOUT && tid < 4) zero_s[tid] = 0.f;
+    float* zero_s = side_s + WIN - HOP;                  // SOUT: HOP zeros (set before the first barrier)
+    if (SOUT && tid < HOP / 4) reinterpret_cast<float4*>(zero_s)[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // Workgroup i is placed on XCD i % 8: the runs are dealt out so that the workgroups of one XCD hold a contiguous
     // range of runs, and neighbouring runs (which read three frames of each other's range) meet in that XCD's L2.
@@ -544,6 +545,68 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
             // then the raw head frames of the own (head samples) or the next run (tail samples) in ascending order
             const float* rec = frames_in + ((long)b * runs_per_utt + ru) * RS;
             const bool has_prev = ru > 0, has_next = ru + 1 < runs_per_utt;
+            // A FULL run (nfr = run = 8 or 16: every run of an utterance but its last) takes the same loads and sums
+            // without branches: ONE buffer resource over [previous | own | next] record, whose out-of-range offsets
+            // return zero - what a sample does not have (no previous / next run, fewer than four covering head frames)
+            // is an offset beyond the resource; which steps of a thread can meet head or tail samples at all is known
+            // at compile time, the others are one load and one store (+ 0: the sum of the generic path's absent terms).
+            auto gather_full = [&](auto nfrc) {
+                constexpr int NFR = decltype(nfrc)::value;
+                constexpr int RSF = 2 * HEAD + HOP * NFR;                 // floats per record at this run length
+                constexpr int HQ = HOP / 4, NPOS = HQ * (NFR + 3), ST = (NPOS + GL_THREADS - 1) / GL_THREADS;
+                constexpr int TAIL0 = HQ * NFR;                          // first group of four of the tail samples
+                constexpr unsigned OOB = 0x80000000u;
+                const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(rec - RSF), 0, (2 + (has_next ? 1 : 0)) * RSF * 4, 0x00020000);
+                auto ld = [&](unsigned off) {
+                    return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs3, off, 0, 0));
+                };
+                f4v ga[ST], gb[ST], gc[ST], gd[ST];
+                const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < ST; ++st) {
+                    const int lo = GL_THREADS * st;
+                    const bool hd = lo < 3 * HQ, tl = lo + GL_THREADS - 1 >= TAIL0;   // (known after unrolling)
+                    const int pp = tid + lo;
+                    ga[st] = gb[st] = gc[st] = gd[st] = zero4;
+                    if (lo + GL_THREADS <= NPOS || pp < NPOS) {
+                        unsigned oa = 4u * (RSF + HEAD) + 16u * (unsigned)pp;
+                        if (hd) {
+                            const unsigned oh = has_prev ? 4u * (HEAD + HOP * NFR) + 16u * (unsigned)pp : OOB;
+                            oa = pp < 3 * HQ ? oh : oa;
+                        }
+                        ga[st] = ld(oa);
+                        if (hd || tl) {
+                            // r = the group's place among the 3 HQ head (tail) groups; frames 0, 1, 2 of the own (next) run
+                            // cover the places from 0, HQ, 2 HQ on
+                            const int r = pp - (hd ? 0 : TAIL0);
+                            const unsigned base = (hd ? 4u * RSF : 8u * RSF) + 16u * (unsigned)r;
+                            gb[st] = ld((unsigned)r < (unsigned)(3 * HQ) ? base : OOB);
+                            gc[st] = ld((unsigned)(r - HQ) < (unsigned)(2 * HQ) ? base + 4u * (HOFF1 - HOP) : OOB);
+                            gd[st] = ld((unsigned)(r - 2 * HQ) < (unsigned)HQ ? base + 4u * (HOFF2 - 2 * HOP) : OOB);
+                        }
+                    }
+                }
+                store_tables();
+#pragma unroll
+                for (int st = 0; st < ST; ++st) {
+                    const int lo = GL_THREADS * st;
+                    const bool hd = lo < 3 * HQ, tl = lo + GL_THREADS - 1 >= TAIL0;
+                    const int pp = tid + lo;
+                    if (lo + GL_THREADS <= NPOS || pp < NPOS) {
+                        f4v y = ga[st] + gb[st];
+                        if (hd || tl) y = (y + gc[st]) + gd[st];
+                        *reinterpret_cast<f4v*>(yseg + 4 * pp) = y;
+                    }
+                }
+            };
+            (void)gather_full;
+#ifndef GL_EXP_OLD_GATHER
+            if (nfr == run && run == 16) gather_full(std::integral_constant<int, 16>());
+            else if (nfr == run && run == 8) gather_full(std::integral_constant<int, 8>());
+            else
+#endif
+            {
             constexpr int STEPS = ((GL_RUN - 1) * HOP + WIN + 4 * GL_THREADS - 1) / (4 * GL_THREADS);
             f4v ga[STEPS], gb[STEPS], gc[STEPS], gd[STEPS];
             const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -551,7 +614,11 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
             for (int st = 0; st < STEPS; ++st) {
                 const int i = 4 * (tid + GL_THREADS * st);
                 ga[st] = gb[st] = gc[st] = gd[st] = zero4;
+#ifdef GL_EXP_NO_GATHER
+                if (false) {
+#else
                 if (i < seg) {
+#endif
                     const float* hp = nullptr;           // record whose raw head frames cover the sample
                     int j = i;                           // ... and the sample's offset in that record's head
                     if (i < HEAD) {
@@ -574,6 +641,7 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
             for (int st = 0; st < STEPS; ++st) {
                 const int i = 4 * (tid + GL_THREADS * st);
                 if (i < seg) *reinterpret_cast<f4v*>(yseg + i) = ((ga[st] + gb[st]) + gc[st]) + gd[st];
+            }
             }
         } else if (m0 >= NOVER - 1 && m0 + nfr + NOVER - 2 <= T - 1) {
             const float* base = fu + (long)(m0 - (NOVER - 1)) * WIN + HOP * (NOVER - 1);   // frame q-3 at offset r + 3 HOP
@@ -685,15 +753,44 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
     //   fft_pad(lane + 64 i) = pr + 68 i, fft_pad(16 lane + c) = 17 lane + c, fft_pad(lane + 256 i) = pr + 272 i,
     //   fft_pad(64 + lane + 256 i) = pr + 68 + 272 i, fft_pad(192 - lane + 256 i) = pm + 272 i, fft_pad(t3l + 256 i)
     //   = pt + 272 i, fft_pad((lane >> 4) 256 + (lane & 15) + 16 c) = pb + 17 c   (checked for every lane, i, c)
+    // (GL_RD: an exchange read. -DGL_EXP_RD64: as a volatile access, which the compiler does not pair into
+    // ds_read2_b64 - 8 LDS-array cycles per two elements against 2 x 2 as plain ds_read_b64)
+#ifdef GL_EXP_RD64
+#define GL_RD(p) (*reinterpret_cast<const volatile cplx*>(p))
+#elif defined(GL_EXP_HALFREAD)   // (experiment, wrong results: every other exchange read dropped: what the reads cost)
+#define GL_RD(p) (*(p))
+#define GL_RDI(p, i) ((i) & 1 ? ({ cplx r_; asm volatile("" : "=v"(r_)); r_; }) : *(p))
+#else
+#define GL_RD(p) (*(p))
+#endif
+#ifndef GL_RDI
+#define GL_RDI(p, i) GL_RD(p)
+#endif
+    // (GL_PIN: behind an exchange's reads. The scheduler, short of registers, otherwise sinks the reads to where their
+    // values are first used - right in front of the wait for them, so that every exchange exposes its read latency
+    // instead of spending it under the other frame's arithmetic.)
+#ifdef GL_EXP_NO_PIN
+#define GL_PIN() do {} while (0)
+#else
+#define GL_PIN() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifdef GL_EXP_ADDTID             // (experiment, wrong results: exchange writes as two ds_write_addtid_b32, lane-linear places)
+#define GL_WRI(p, i, val) do { const cplx v__ = (val); asm volatile("ds_write_addtid_b32 %0 offset:%2\n\tds_write_addtid_b32 %1 offset:%3" :: "v"(v__.x), "v"(v__.y), "n"(256 * ((i) & 15)), "n"(4352 + 256 * ((i) & 15)) : "memory"); } while (0)
+#elif defined(GL_EXP_HALFWRITE)          // (experiment, wrong results: every other exchange write dropped)
+#define GL_WRI(p, i, val) do { if (!((i) & 1)) *(p) = (val); else asm volatile("" :: "v"(val)); } while (0)
+#else
+#define GL_WRI(p, i, val) (*(p) = (val))
+#endif
     cplx* const l_r = lds + lane + (lane >> 4);
     cplx* const l_17 = lds + 17 * lane;
     cplx* const l_b = lds + (lane >> 4) * 272 + (lane & 15);
     cplx* const l_m = lds + (192 - lane) + ((192 - lane) >> 4);
     auto x_pass1 = [&](Fr& f) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) l_17[c] = f.v[c];
+        for (int c = 0; c < 16; ++c) GL_WRI(l_17 + c, c, f.v[c]);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) f.v[i] = l_r[68 * i];
+        for (int i = 0; i < 16; ++i) f.v[i] = GL_RDI(l_r + 68 * i, i);
+        GL_PIN();
     };
     // Pass 2 writes y2[(t - k) 16 + k + 16 c]; the radix-4 pass that follows reads butterfly t's inputs y2[t + 256 i].
     // Which four butterflies a lane takes is free: here t = l, 64 + l, 192 - l, 256 - l (lane 0: 0, 64, 192, 128), so
@@ -703,14 +800,15 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
     cplx* const l_t = lds + t3l + (t3l >> 4);
     auto x_pass2 = [&](Fr& f) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) l_b[17 * c] = f.v[c];
+        for (int c = 0; c < 16; ++c) GL_WRI(l_b + 17 * c, c, f.v[c]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f.v[4 * i] = l_r[272 * i];
-            f.v[4 * i + 1] = l_r[68 + 272 * i];
-            f.v[4 * i + 2] = l_m[272 * i];
-            f.v[4 * i + 3] = l_t[272 * i];
+            f.v[4 * i] = GL_RDI(l_r + 272 * i, 0);
+            f.v[4 * i + 1] = GL_RDI(l_r + 68 + 272 * i, 1);
+            f.v[4 * i + 2] = GL_RDI(l_m + 272 * i, 0);
+            f.v[4 * i + 3] = GL_RDI(l_t + 272 * i, 1);
         }
+        GL_PIN();
     };
     auto m2f = [&](Fr& f) {
         cplx (&v)[16] = f.v;
@@ -746,7 +844,7 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
             cplx Wk[4], E[4], Tt[4], Xk[4], Un[4];       // are one statement each
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                Wk[j] = wk_s[lane + 64 * (h + j)];
+                Wk[j] = GL_RD(wk_s + lane + 64 * (h + j));
                 const cplx zk = f.v[RK[h + j]];
                 const cplx cn = cconj(f.v[RN[h + j]]);
                 E[j] = cadd(zk, cn);
@@ -790,13 +888,14 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
     auto x3 = [&](Fr& f) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            l_r[272 * i] = f.v[4 * i];
-            l_r[68 + 272 * i] = f.v[4 * i + 1];
-            l_m[272 * i] = f.v[4 * i + 2];
-            l_t[272 * i] = f.v[4 * i + 3];
+            GL_WRI(l_r + 272 * i, 0, f.v[4 * i]);
+            GL_WRI(l_r + 68 + 272 * i, 1, f.v[4 * i + 1]);
+            GL_WRI(l_m + 272 * i, 0, f.v[4 * i + 2]);
+            GL_WRI(l_t + 272 * i, 1, f.v[4 * i + 3]);
         }
 #pragma unroll
-        for (int c = 0; c < 16; ++c) f.v[c] = l_b[17 * c];
+        for (int c = 0; c < 16; ++c) f.v[c] = GL_RDI(l_b + 17 * c, c);
+        GL_PIN();
     };
     // pass 2 backwards: inverse 16-point DFT, then the conjugate twiddles (tw = T2 again, read once per pair)
     auto m2i = [&](Fr& f) {
@@ -809,9 +908,10 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
     };
     auto x4 = [&](Fr& f) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) l_r[68 * i] = f.v[i];
+        for (int i = 0; i < 16; ++i) GL_WRI(l_r + 68 * i, i, f.v[i]);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) f.v[c] = l_17[c];
+        for (int c = 0; c < 16; ++c) f.v[c] = GL_RDI(l_17 + c, c);
+        GL_PIN();
     };
     // pass 1 backwards: v[i] = 1024 z'[lane + 64 i]; window, store (the two frames of a pair separately: sharing the
     // window read between them bunches their stores and measured slower, 7.45 against 7.34 ms)
@@ -934,10 +1034,71 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
         }
     };
 
+    // The same pass for a FULL round of eight frames (all rounds of a full run: every run of an utterance but its
+    // last), written so that almost nothing of it is per-lane arithmetic: thread t < 225 takes the hops Q0 + 3 u + h0
+    // (h0 = t / 75, u = 0..3; Q0 = 2 / 8 in round 0 / 1), four samples at t % 75 of each. With that dealing every unit u
+    // is uniform in what the generic pass decides per lane: where the sum is built up (hops 8..10 of the run: the side
+    // buffer), whether it is complete (record) or goes on in the next round (LDS), and the place of a contributing
+    // frame's buffer is one of three constants chosen by h0. Same sums in the same order, same zeros for the
+    // contributions a round does not have: same bits (217 -> ~80 VALU instructions a wave and round).
+    auto pass_full = [&](auto rdc) {
+        constexpr int RD = decltype(rdc)::value;
+        static_assert(HEAD == 3 * HOP && GL_WAVES == 4 && HOP % 4 == 0, "pass_full: eight frames a round, three head hops");
+        constexpr int F0 = 8 * RD, Q0 = RD ? 8 : 2, NU = RD ? 4 : 3, HQ = HOP / 4;
+        const bool last = F0 + 8 == nfr;                 // (round 1 of a full run: always)
+        int t = lane_ + 64 * wave;
+        asm volatile("" : "+v"(t));
+        const bool act = t < 3 * HQ;
+        t = min(t, 3 * HQ - 1);
+        const int h0 = (t >= HQ) + (t >= 2 * HQ);
+        const int lp = HOP * h0 + 4 * (t - HQ * h0);     // the lane's part of a sample index: hop h0, group t % 75
+        const int o4 = 4 * (t - HQ * h0);
+        const float* pbase = reinterpret_cast<const float*>(fft_s);
+        const int zoff = (int)(zero_s - pbase);
+        f4v a[NU], c[NU][3];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            constexpr int dummy = 0; (void)dummy;
+            const int qb = Q0 + 3 * u;                   // hop of the lanes with h0 = 0
+            const bool side = qb == 2 * GL_WAVES;        // hops 8, 9, 10
+            const float* ab = side ? side_s + (HOP * qb - 2 * GL_WAVES * HOP) : yseg + HOP * qb;
+            a[u] = *reinterpret_cast<const f4v*>(ab + lp);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                // frame fq = qb + h0 - 2 + d of the run, g = fq - F0 of the round: buffer of wave g & 3, slot g >> 2
+                const int g0 = qb - 2 + d - F0;
+                int off[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int g = g0 + k;
+                    off[k] = (g >= 0 && g < 8) ? (g & 3) * (2 * GL2_LDS) + ((g >> 2) & 1) * HEAD + HOP * (2 - d) : zoff;
+                }
+                const int sel = h0 == 0 ? off[0] : (h0 == 1 ? off[1] : off[2]);
+                c[u][d] = *reinterpret_cast<const f4v*>(pbase + sel + o4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int qb = Q0 + 3 * u;
+            const bool side = qb == 2 * GL_WAVES;
+            const bool ok = act && qb + h0 >= (RD ? F0 : HEAD / HOP) && qb + h0 < F0 + 8 + HEAD / HOP;
+            const bool fin = last || qb + 2 < F0 + 8;    // (uniform: the units' hops do not straddle the round's end)
+            const f4v acc = ((a[u] + c[u][0]) + c[u][1]) + c[u][2];
+            if (ok) {
+                if (fin) rec_store4(HEAD + HOP * qb + lp, acc);
+                else *reinterpret_cast<f4v*>((side ? side_s + (HOP * qb - 2 * GL_WAVES * HOP) : yseg + HOP * qb) + lp) = acc;
+            }
+        }
+    };
+
+    (void)pass_full;
     // frames of this wave: wave, wave + 4, ...; two at a time, half a stage apart: while one frame's exchange is in
     // flight the other frame computes. A last, single frame runs as a pair with itself (the copy is not stored).
     // SOUT: a round (the workgroup's next eight frames) is bracketed by workgroup barriers, so every wave takes every
     // round, with or without a frame of its own in it.
+#ifdef GL_EXP_ADDTID
+    asm volatile("s_mov_b32 m0, %0" :: "s"((unsigned)(size_t)lds) : "memory");
+#endif
     const int nrounds = SOUT ? (nfr + 2 * GL_WAVES - 1) / (2 * GL_WAVES) : 1;
     for (int rd = 0; rd < nrounds; ++rd) {
         for (int fi = wave + (SOUT ? 2 * GL_WAVES * rd : 0); fi < (SOUT ? min(nfr, 2 * GL_WAVES * (rd + 1)) : nfr);
@@ -998,7 +1159,15 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
             if (wave + 2 * GL_WAVES * rd >= nfr) gl_lds_barrier();      // (B1)
             gl_lds_barrier();                                           // (B2) the round's contributions are in LDS
             GL_STAMP(24 + 3 * rd);
-            pass(rd);
+#ifndef GL_EXP_NO_PASS   // (experiment, wrong results: what the summation pass costs)
+#ifndef GL_EXP_OLD_PASS
+            if (min(nfr, 2 * GL_WAVES * (rd + 1)) - 2 * GL_WAVES * rd == 2 * GL_WAVES && rd < 2) {
+                if (rd == 0) pass_full(std::integral_constant<int, 0>());
+                else pass_full(std::integral_constant<int, 1>());
+            } else
+#endif
+                pass(rd);
+#endif
             GL_STAMP(25 + 3 * rd);
             if (rd + 1 < nrounds) gl_lds_barrier();                     // (B3) before the buffers are written again
             GL_STAMP(26 + 3 * rd);
@@ -1122,7 +1291,7 @@ int launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, fl
         const int sout = sin || (state && gl2_records_ok(p, T, run, (long)B * runs_per_utt)) ? 1 : 0;
         const size_t lds = (size_t)(((run - 1) * p.hop + p.win + 3) & ~3) * 4 + (size_t)p.win * 4 +
                            (size_t)(FFT_TW + FFT_N / 2 + GL_WAVES * GL2_LDS) * sizeof(cplx) +
-                           (sout ? (size_t)(p.win - p.hop) * 4 + 16 : 0);
+                           (sout ? (size_t)(p.win - p.hop) * 4 + (size_t)p.hop * 4 : 0);
         auto* kern = sin ? gl_iter2_kernel<1200, 300, true, true>
                          : (sout ? gl_iter2_kernel<1200, 300, false, true> : gl_iter2_kernel<1200, 300, false, false>);
         // (records in -> records out always: eligibility depends on T and the run only, which a chain does not change)
