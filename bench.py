@@ -200,6 +200,8 @@ def main():
     ap.add_argument('--decode-mode', type=int, default=2,
                     help='0 eager per-stage kernels, 1 hipGraph, 2 persistent kernel (32 workgroups per 16 utterances: '
                          'latency), 3 tile kernel (one workgroup per 16 utterances: throughput, wants --streams >= 12)')
+    ap.add_argument('--bigru-mode', type=int, default=0,
+                    help='CBHG BiGRU scan in the throughput legs: 0 = one utterance per workgroup, 1 = sixteen on MFMA')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
@@ -326,11 +328,15 @@ def main():
         if os.environ.get('TACO_BENCH_DECODES'):             # (tuning) decodes allowed side by side, 0 = no limit
             budget = int(os.environ['TACO_BENCH_DECODES']) * 32 * ((B + 15) // 16)
         eng.set_persist_budget(budget)
+        for e in engines:
+            e.set_bigru_mode(args.bigru_mode)
         t0 = time.perf_counter()
         for _ in range(n_steps):
             step(to_wav)
         barrier()
         el = time.perf_counter() - t0
+        for e in engines:
+            e.set_bigru_mode(0)
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=eng.device if dist.get_backend() == 'nccl' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

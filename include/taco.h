@@ -225,6 +225,15 @@ int32_t taco_get_persist_budget(int32_t device);
  * throughput: default 1. Ignored under stream capture and while launches are being timed. */
 int taco_set_gl_split(taco_handle h, int32_t groups);
 
+/* Scheduling knob of the CBHG's bidirectional GRU (model/modules.py:92-98; no reference counterpart: TF picks its own
+ * kernels). 0 (default): one workgroup scans one direction of ONE utterance (0.64 us per time step, 2 B workgroups of a
+ * CU each: the latency path, and the only one for cell counts other than 128). 1: one workgroup scans one direction of
+ * SIXTEEN utterances with the recurrent products on fp32 MFMA (~2.6 us per time step, B / 8 workgroups): a quarter of
+ * the CU time per batch, for callers that keep several batches in flight. Both modes compute each utterance
+ * independently of what it is batched with, in a fixed summation order of their own: results are batch-invariant
+ * within a mode and differ between the modes in the last bits (both are tested against the oracle). */
+int taco_set_bigru_mode(taco_handle h, int32_t mode);
+
 /* Synchronous check of the last persistent decode (reads a few device words; call after the stream has been
  * synchronised): <0 if one of its bounded inter-workgroup waits timed out, in which case its outputs are invalid.
  * Failure handling of the persistent mode (no reference counterpart; the reference's loop is a tf.while_loop inside

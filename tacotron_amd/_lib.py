@@ -33,7 +33,7 @@ class TacoWeightEntry(ctypes.Structure):
 
 EXPORTS = ['taco_last_error', 'taco_create', 'taco_destroy', 'taco_workspace_bytes', 'taco_encode',
            'taco_decode', 'taco_decode_teacher', 'taco_postnet', 'taco_griffin_lim', 'taco_griffin_lim_noalloc', 'taco_griffin_lim_librosa', 'taco_spectrogram', 'taco_spectrogram_workspace_bytes', 'taco_synthesize', 'taco_timing_begin',
-           'taco_timing_end', 'taco_kernel_name', 'taco_num_kernel_kinds', 'taco_set_decode_graph', 'taco_set_persist_budget', 'taco_get_persist_budget', 'taco_set_gl_split', 'taco_decode_status', 'taco_debug_conv_gemm', 'taco_debug_handoff_probe',
+           'taco_timing_end', 'taco_kernel_name', 'taco_num_kernel_kinds', 'taco_set_decode_graph', 'taco_set_persist_budget', 'taco_get_persist_budget', 'taco_set_gl_split', 'taco_set_bigru_mode', 'taco_decode_status', 'taco_debug_conv_gemm', 'taco_debug_handoff_probe',
            'taco_debug_poison_decoder']
 
 _lib = None
@@ -88,6 +88,8 @@ def load_library():
     lib.taco_set_persist_budget.argtypes = [i32, i32]
     lib.taco_set_gl_split.restype = ctypes.c_int
     lib.taco_set_gl_split.argtypes = [vp, i32]
+    lib.taco_set_bigru_mode.restype = ctypes.c_int
+    lib.taco_set_bigru_mode.argtypes = [vp, i32]
     lib.taco_get_persist_budget.restype = i32
     lib.taco_get_persist_budget.argtypes = [i32]
     lib.taco_spectrogram_workspace_bytes.restype = sz

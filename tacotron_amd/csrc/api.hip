@@ -83,6 +83,7 @@ struct CbhgW {
     ConvW rnn_in;            // N = 6*gru: [fw gates | fw cand | bw gates | bw cand]
     float* Pg = nullptr;     // [2][64][512]
     float* Pc = nullptr;     // [2][32][512]
+    float* Pm = nullptr;     // [2][8][96][64]: the A-operand image of bigru_scan_mfma_kernel (128 cells only)
 };
 
 struct GraphEntry {
@@ -123,6 +124,7 @@ struct taco_ctx {
     hipStream_t gl_streams[3] = {nullptr, nullptr, nullptr};
     hipEvent_t gl_fork = nullptr, gl_join[3] = {nullptr, nullptr, nullptr};
     int gl_split = 1;              // taco_set_gl_split: utterance groups of a Griffin-Lim call on streams of their own
+    int bigru_mode = 0;            // taco_set_bigru_mode: 0 = one utterance per workgroup (latency), 1 = sixteen on MFMA
     bool status_pending = false;
     bool persist_broken = false;
     unsigned long long* dbg_stamps = nullptr;  // PD_STAMPS builds: 64 s_memrealtime stamps of one step
@@ -344,6 +346,22 @@ struct Loader {
             cb.Pg = upload(pg);
             cb.Pc = upload(pc);
             if (!cb.Pg || !cb.Pc) return false;
+            // ... and the A-operand image of the throughput variant: wave w owns cells 16 w .. 16 w + 15; register
+            // 32 kind + 4 g + m (kind = reset / update / candidate) of lane l is W_kind[k = 16 g + 4 (l / 16) + m][cell
+            // 16 w + l % 16], the k order in which the state's float4 quads reach the MFMAs (rnn.hip)
+            std::vector<float> pm((size_t)2 * 8 * 96 * 64);
+            for (int d = 0; d < 2; ++d)
+                for (int w = 0; w < 8; ++w)
+                    for (int i = 0; i < 96; ++i)
+                        for (int l = 0; l < 64; ++l) {
+                            const int kind = i / 32, gm = i % 32, k = 16 * (gm / 4) + 4 * (l / 16) + (gm % 4);
+                            const int n = 16 * w + (l % 16);
+                            pm[(((size_t)d * 8 + w) * 96 + i) * 64 + l] =
+                                kind == 2 ? ck[d]->data[(size_t)(D + k) * G + n]
+                                          : gk[d]->data[(size_t)(D + k) * 2 * G + (kind == 1 ? G : 0) + n];
+                        }
+            cb.Pm = upload(pm);
+            if (!cb.Pm) return false;
         }
         return true;
     }
@@ -546,7 +564,8 @@ int run_cbhg(taco_ctx* c, const CbhgW& cb, const float* x, const int32_t* lens, 
         t.out = xp; t.ldo = 6 * cb.gru;
         launch_cbhg_tail(t, s, tm);
 #ifndef TACO_EXP_NO_BIGRU   // (timing experiment, wrong results: what the chip does with the scan's work gone)
-        launch_bigru_scan(xp, cb.Pg, cb.Pc, lens, out, B, T, cb.gru, s, tm);
+        if (c->bigru_mode == 1 && cb.Pm) launch_bigru_scan_mfma(xp, cb.Pm, lens, out, B, T, s, tm);
+        else launch_bigru_scan(xp, cb.Pg, cb.Pc, lens, out, B, T, cb.gru, s, tm);
 #else
         (void)hipMemsetAsync(out, 0, (size_t)M * 2 * cb.gru * sizeof(float), s);
 #endif
@@ -566,7 +585,8 @@ int run_cbhg(taco_ctx* c, const CbhgW& cb, const float* x, const int32_t* lens, 
     g = GemmArgs{h, cb.highway_depth, M, T, cb.rnn_in.Cin, 1, 0, cb.rnn_in.W, cb.rnn_in.ldw, cb.rnn_in.N,
                  cb.rnn_in.bias, nullptr, nullptr, nullptr, 0, xp, 6 * cb.gru, ACT_NONE, 0};
     launch_conv_gemm(g, s, tm);
-    launch_bigru_scan(xp, cb.Pg, cb.Pc, lens, out, B, T, cb.gru, s, tm);
+    if (c->bigru_mode == 1 && cb.Pm) launch_bigru_scan_mfma(xp, cb.Pm, lens, out, B, T, s, tm);
+    else launch_bigru_scan(xp, cb.Pg, cb.Pc, lens, out, B, T, cb.gru, s, tm);
     return 0;
 }
 
@@ -1469,6 +1489,13 @@ extern "C" int taco_set_gl_split(taco_handle h, int32_t groups) {
     if (!h) return fail("taco_set_gl_split: null handle");
     if (groups < 1 || groups > 4) return fail("taco_set_gl_split: groups must be 1..4");
     h->gl_split = groups;
+    return 0;
+}
+
+extern "C" int taco_set_bigru_mode(taco_handle h, int32_t mode) {
+    if (!h) return fail("taco_set_bigru_mode: null handle");
+    if (mode != 0 && mode != 1) return fail("taco_set_bigru_mode: mode must be 0 (latency) or 1 (throughput)");
+    h->bigru_mode = mode;
     return 0;
 }
 

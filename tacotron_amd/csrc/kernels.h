@@ -96,6 +96,10 @@ void launch_embed_gather(const int32_t* ids, const float* lut, float* out, int M
 // any other G: Pg [2][G][2G], Pc [2][G][G], the recurrent halves k-major (bigru_scan_generic_kernel).
 constexpr int BIGRU_H = 128;
 constexpr int BIGRU_THREADS = 512;
+// Throughput variant for G = 128 (bigru_scan_mfma_kernel): sixteen utterances per workgroup on fp32 MFMA; Pm
+// [2 directions][8 waves][96][64 lanes] is the A-operand register image (api.hip).
+void launch_bigru_scan_mfma(const float* xp, const float* Pm, const int32_t* lens, float* out, int B, int T,
+                            hipStream_t s, Timing* tm);
 void launch_bigru_scan(const float* xp, const float* Pg, const float* Pc, const int32_t* lens, float* out,
                        int B, int T, int G, hipStream_t s, Timing* tm);
 

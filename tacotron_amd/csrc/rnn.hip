@@ -208,6 +208,126 @@ __global__ __launch_bounds__(BIGRU_GEN_THREADS) void bigru_scan_generic_kernel(
     }
 }
 
+// The same recurrence as a THROUGHPUT variant (taco_set_bigru_mode 1; 128 cells): one 512-thread workgroup scans one
+// direction of SIXTEEN utterances in lockstep, the recurrent products on v_mfma_f32_16x16x4_f32 (exact f32, a fixed k
+// order that does not depend on the batch). The weights are the A operand and stay in registers for all T steps (wave
+// w owns the 16 cells 16 w .. 16 w + 15: its reset, update and candidate tiles, 3 x 32 = 96 registers per lane); the
+// state is the B operand. A lane holds its C/D fragment (cells n0 .. n0 + 3 of utterance `col`) as one float4, and
+// that float4, stored as quad (n0 / 4, col) of a [32 quads][16 utterances] LDS image, is at once what an MFMA group
+// reads back as B: lane l takes quad (4 g + l / 16, l % 16) and feeds its component m to MFMA (g, m), which therefore
+// sums over k = 16 g + 4 (l / 16) + m - the weights are packed to that order (api.hip). Per step and wave: 8 + 8
+// ds_read_b128, 96 MFMAs (6144 MFMA cycles a SIMD: ~2.6 us a step, against 0.64 us for the one-utterance kernel), 2
+// barriers; but 4 workgroups scan a batch of 32 instead of 64, ~12 CU-ms instead of ~49 per post-net scan: the
+// variant for several batches in flight, where CU time, not latency, is what a scan costs. Same TF gate order (reset
+// gate applied to the state BEFORE the candidate matmul, modules.py:92-98 / A.5), same masking (A.6): a column past
+// its length keeps its state and emits nothing (its rows were zeroed up front); the backward direction walks each
+// column's own first `len` steps reversed.
+constexpr int BIGRU_MFMA_THREADS = 512;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(BIGRU_MFMA_THREADS) void bigru_scan_mfma_kernel(
+    const float* __restrict__ xp, const float* __restrict__ Pm, const int32_t* __restrict__ lens,
+    float* __restrict__ out, int B, int T) {
+    constexpr int H = BIGRU_H;
+    static_assert(H == 128 && BIGRU_MFMA_THREADS == 512, "eight waves of 16 cells each");
+    __shared__ __attribute__((aligned(16))) f32x4 hq[2][32 * 16];     // state, [quad of cells][utterance]
+    __shared__ __attribute__((aligned(16))) f32x4 rhq[32 * 16];       // r * h
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y;
+    const int col = lane & 15, rq = lane >> 4;
+    const int b = blockIdx.x * 16 + col;
+    const bool has_b = b < B;
+    const int bc = has_b ? b : B - 1;                                // (addresses only: a padding column never stores)
+    auto clamp_len = [&](int i) { const int l = lens ? lens[i] : T; return l < 0 ? 0 : (l > T ? T : l); };
+    const int len = has_b ? clamp_len(b) : 0;
+    int maxlen = 0;
+    for (int c = 0; c < 16; ++c) {
+        const int bb = blockIdx.x * 16 + c;
+        if (bb < B) maxlen = max(maxlen, clamp_len(bb));
+    }
+    // zero the outputs of masked steps (this direction's half of the rows past each column's length)
+    for (int c = 0; c < 16; ++c) {
+        const int bb = blockIdx.x * 16 + c;
+        if (bb >= B) break;
+        const int lc = clamp_len(bb);
+        float* orow = out + ((size_t)bb * T + lc) * (2 * H) + dir * H;
+        for (int i = tid; i < (T - lc) * (H / 4); i += BIGRU_MFMA_THREADS)
+            *reinterpret_cast<f32x4*>(orow + (size_t)(i / (H / 4)) * 2 * H + 4 * (i % (H / 4))) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float wa[96];
+#pragma unroll
+    for (int i = 0; i < 96; ++i) wa[i] = Pm[(((size_t)dir * 8 + wave) * 96 + i) * 64 + lane];
+    const int n0 = 16 * wave + 4 * rq;                               // the lane's four cells
+    const int myq = (4 * wave + rq) * 16 + col;                      // ... as a quad of the LDS images
+    f32x4 h_own = {0.f, 0.f, 0.f, 0.f};
+    hq[0][myq] = h_own;
+    const float* xb = xp + (size_t)bc * T * (6 * H) + dir * 3 * H + n0;
+    float* ob = out + (size_t)bc * T * (2 * H) + dir * H + n0;
+    auto tpos = [&](int s) { const int sc = min(s, len - 1); return len > 0 ? (dir == 0 ? sc : len - 1 - sc) : 0; };
+    auto loadx = [&](int s, f32x4& xr, f32x4& xu, f32x4& xc) {
+        const float* p = xb + (size_t)tpos(s) * (6 * H);
+        xr = *reinterpret_cast<const f32x4*>(p);
+        xu = *reinterpret_cast<const f32x4*>(p + H);
+        xc = *reinterpret_cast<const f32x4*>(p + 2 * H);
+    };
+    f32x4 xr, xu, xc, xr_n, xu_n, xc_n;
+    loadx(0, xr, xu, xc);
+    __syncthreads();
+    for (int s = 0; s < maxlen; ++s) {
+        const int cur = s & 1;
+        loadx(s + 1, xr_n, xu_n, xc_n);                              // (one step ahead: a step is ~2.6 us)
+        f32x4 ar = {0.f, 0.f, 0.f, 0.f}, au = ar;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 hb = hq[cur][64 * g + lane];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[4 * g + m], hb[m], ar, 0, 0, 0);
+                au = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[32 + 4 * g + m], hb[m], au, 0, 0, 0);
+            }
+        }
+        f32x4 r, u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r[j] = sigmoidf_(ar[j] + xr[j]);
+            u[j] = sigmoidf_(au[j] + xu[j]);
+        }
+        rhq[myq] = r * h_own;
+        __syncthreads();
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;                    // (two chains: dependent MFMAs do not issue back to back)
+#pragma unroll
+        for (int g = 0; g < 8; g += 2) {
+            const f32x4 r0 = rhq[64 * g + lane], r1 = rhq[64 * (g + 1) + lane];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[64 + 4 * g + m], r0[m], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[64 + 4 * (g + 1) + m], r1[m], a1, 0, 0, 0);
+            }
+        }
+        const f32x4 ac = a0 + a1;
+        if (s < len) {
+            f32x4 hn;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float c = tanhf_(ac[j] + xc[j]);
+                hn[j] = u[j] * h_own[j] + (1.f - u[j]) * c;
+            }
+            h_own = hn;
+            *reinterpret_cast<f32x4*>(ob + (size_t)tpos(s) * (2 * H)) = hn;
+        }
+        hq[cur ^ 1][myq] = h_own;
+        xr = xr_n; xu = xu_n; xc = xc_n;
+        __syncthreads();
+    }
+}
+
+void launch_bigru_scan_mfma(const float* xp, const float* Pm, const int32_t* lens, float* out, int B, int T,
+                            hipStream_t s, Timing* tm) {
+    if (tm) tm->begin(KK_BIGRU, s);
+    hipLaunchKernelGGL(bigru_scan_mfma_kernel, dim3((B + 15) / 16, 2), dim3(BIGRU_MFMA_THREADS), 0, s, xp, Pm, lens, out,
+                       B, T);
+    if (tm) tm->end(KK_BIGRU, s);
+}
+
 void launch_bigru_scan(const float* xp, const float* Pg, const float* Pc, const int32_t* lens, float* out,
                        int B, int T, int G, hipStream_t s, Timing* tm) {
     if (tm) tm->begin(KK_BIGRU, s);

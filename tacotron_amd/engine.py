@@ -129,6 +129,11 @@ class TacoEngine:
         better setting for a batch that has the GPU to itself, 1 (default) with several batches in flight."""
         self._check(self.lib.taco_set_gl_split(self.handle, int(groups)))
 
+    def set_bigru_mode(self, mode):
+        """CBHG BiGRU scan: 0 = one utterance per workgroup (latency, default), 1 = sixteen per workgroup on fp32 MFMA
+        (a quarter of the CU time: the setting for several batches in flight). include/taco.h."""
+        self._check(self.lib.taco_set_bigru_mode(self.handle, int(mode)))
+
     def get_persist_budget(self):
         return int(self.lib.taco_get_persist_budget(int(self.device.index or 0)))
 

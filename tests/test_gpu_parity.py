@@ -539,3 +539,40 @@ def test_very_long_input(engine, hp, weights):
     o = engine.finish(engine.synthesize(ids, lens, max_iters=2))
     for name in ('enc_out', 'mel', 'linear', 'alignments'):
         assert rel_l1(_np(o[name]), ref[name]) < 1e-3, name
+
+
+@pytest.mark.parametrize('B,T_in', [(1, 5), (3, 37), (17, 40), (33, 21)])
+def test_encode_bigru_mfma_mode(engine, hp, weights, B, T_in):
+    """The throughput variant of the BiGRU scan (taco_set_bigru_mode 1: sixteen utterances per workgroup on fp32 MFMA)
+    against the oracle through the encoder, ragged lengths, batches that fill one, two and three column groups partly;
+    padded steps exactly zero; an utterance's result does not depend on what it is batched with."""
+    rng = np.random.default_rng(100 * B + T_in)
+    ids, lens = synth_ids(rng, B, T_in)
+    ref = O.encode(ids, lens, O.cast_weights(weights, np.float64), hp)
+    engine.set_bigru_mode(1)
+    try:
+        got = _np(engine.encode(ids, lens))
+        alone = _np(engine.encode(ids[B - 1:B], lens[B - 1:B]))
+    finally:
+        engine.set_bigru_mode(0)
+    for b in range(B):
+        assert np.all(got[b, lens[b]:] == 0)
+    assert rel_l1(got, ref) < 1e-4, rel_l1(got, ref)
+    assert np.array_equal(alone[0], got[B - 1])
+    base = _np(engine.encode(ids, lens))
+    assert rel_l1(got, base) < 1e-5
+
+
+@pytest.mark.parametrize('B,T', [(2, 15), (3, 100), (18, 60), (2, 1000)])
+def test_postnet_bigru_mfma_mode(engine, hp, weights, B, T):
+    rng = np.random.default_rng(B + T)
+    mel = (0.3 * rng.standard_normal((B, T, 80))).astype(np.float32)
+    ref = O.postnet(mel.astype(np.float64), O.cast_weights(weights, np.float64), hp)
+    engine.set_bigru_mode(1)
+    try:
+        got = _np(engine.postnet(mel))
+        one = _np(engine.postnet(mel[1:2]))
+    finally:
+        engine.set_bigru_mode(0)
+    assert rel_l1(got, ref) < 1e-4, rel_l1(got, ref)
+    assert np.array_equal(one[0], got[1])

@@ -1,0 +1,11 @@
+# throughput with the BiGRU scan in latency (0) / throughput (1) mode, mel + linear and to the waveform, one box
+set -o pipefail
+O=gpurun_out/r03; mkdir -p $O
+for leg in "" "--to-wav --steps 60"; do
+for m in 0 1 0 1; do
+  timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --no-roofline --bigru-mode $m $leg > $O/bigru_ab.json 2> $O/bigru_ab.err || { tail -5 $O/bigru_ab.err; exit 1; }
+  python3 -c "
+import json
+d = json.loads([l for l in open('$O/bigru_ab.json') if l.startswith('{')][-1])
+print('leg=[$leg] bigru_mode=$m frames/s %.4g ms/step %.3f p50 batch latency %.2f' % (d['value'], d['ms_per_step'], d['p50_batch_latency_ms']))"
+done; done

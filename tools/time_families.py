@@ -11,6 +11,7 @@ from tacotron_amd.weights import init_weights
 from tacotron_amd.data.synthetic import synth_ids
 hp = HParams()
 eng = TacoEngine(init_weights(hp, seed=1234), hp)
+eng.set_bigru_mode(int(os.environ.get('TACO_BIGRU_MODE', '0')))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 ids, lens = synth_ids(np.random.default_rng(0), B, 150, ragged=False)
 ids_d, lens_d = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
