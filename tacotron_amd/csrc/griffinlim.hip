@@ -1291,7 +1291,11 @@ int launch_gl_iter(const GLPlan& p, const float* frames_in, const float* mag, fl
         const int sout = sin || (state && gl2_records_ok(p, T, run, (long)B * runs_per_utt)) ? 1 : 0;
         const size_t lds = (size_t)(((run - 1) * p.hop + p.win + 3) & ~3) * 4 + (size_t)p.win * 4 +
                            (size_t)(FFT_TW + FFT_N / 2 + GL_WAVES * GL2_LDS) * sizeof(cplx) +
-                           (sout ? (size_t)(p.win - p.hop) * 4 + (size_t)p.hop * 4 : 0);
+                           (sout ? (size_t)(p.win - p.hop) * 4 + (size_t)p.hop * 4 : 0)
+#ifdef GL_EXP_ONE_WG                         // (experiment: dynamic LDS padded so that only one workgroup fits a CU)
+                           + 8192
+#endif
+            ;
         auto* kern = sin ? gl_iter2_kernel<1200, 300, true, true>
                          : (sout ? gl_iter2_kernel<1200, 300, false, true> : gl_iter2_kernel<1200, 300, false, false>);
         // (records in -> records out always: eligibility depends on T and the run only, which a chain does not change)
