@@ -753,17 +753,13 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
     //   fft_pad(lane + 64 i) = pr + 68 i, fft_pad(16 lane + c) = 17 lane + c, fft_pad(lane + 256 i) = pr + 272 i,
     //   fft_pad(64 + lane + 256 i) = pr + 68 + 272 i, fft_pad(192 - lane + 256 i) = pm + 272 i, fft_pad(t3l + 256 i)
     //   = pt + 272 i, fft_pad((lane >> 4) 256 + (lane & 15) + 16 c) = pb + 17 c   (checked for every lane, i, c)
-    // (GL_RD: an exchange read. -DGL_EXP_RD64: as a volatile access, which the compiler does not pair into
-    // ds_read2_b64 - 8 LDS-array cycles per two elements against 2 x 2 as plain ds_read_b64)
-#ifdef GL_EXP_RD64
-#define GL_RD(p) (*reinterpret_cast<const volatile cplx*>(p))
-#elif defined(GL_EXP_HALFREAD)   // (experiment, wrong results: every other exchange read dropped: what the reads cost)
+    // (GL_RD / GL_RDI / GL_WRI: an exchange's reads and writes; the experiment builds below price them. As plain
+    // accesses the compiler pairs the reads into ds_read2_b64 - 8 LDS-array cycles per two elements against 2 x 2 as
+    // ds_read_b64; forcing the single form with volatile accesses made the register allocation spill 655 registers.)
 #define GL_RD(p) (*(p))
+#ifdef GL_EXP_HALFREAD   // (experiment, wrong results: every other exchange read dropped, the value left undefined)
 #define GL_RDI(p, i) ((i) & 1 ? ({ cplx r_; asm volatile("" : "=v"(r_)); r_; }) : *(p))
 #else
-#define GL_RD(p) (*(p))
-#endif
-#ifndef GL_RDI
 #define GL_RDI(p, i) GL_RD(p)
 #endif
     // (GL_PIN: behind an exchange's reads. The scheduler, short of registers, otherwise sinks the reads to where their
@@ -1058,7 +1054,6 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
         f4v a[NU], c[NU][3];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            constexpr int dummy = 0; (void)dummy;
             const int qb = Q0 + 3 * u;                   // hop of the lanes with h0 = 0
             const bool side = qb == 2 * GL_WAVES;        // hops 8, 9, 10
             const float* ab = side ? side_s + (HOP * qb - 2 * GL_WAVES * HOP) : yseg + HOP * qb;
