@@ -576,3 +576,22 @@ def test_postnet_bigru_mfma_mode(engine, hp, weights, B, T):
         engine.set_bigru_mode(0)
     assert rel_l1(got, ref) < 1e-4, rel_l1(got, ref)
     assert np.array_equal(one[0], got[1])
+
+
+def test_bigru_mfma_mode_edge_lengths(engine, hp, weights):
+    """Throughput BiGRU scan: utterances of length 0, 1 and T among full ones in a batch that leaves a column group
+    partly empty; against the one-utterance kernel (different summation order: 1e-5) and the masking rule (A.6)."""
+    rng = np.random.default_rng(77)
+    B, T_in = 21, 9
+    ids, lens = synth_ids(rng, B, T_in)
+    lens[1], lens[2], lens[5], lens[20] = 0, 1, T_in, 1
+    base = _np(engine.encode(ids, lens))
+    engine.set_bigru_mode(1)
+    try:
+        got = _np(engine.encode(ids, lens))
+    finally:
+        engine.set_bigru_mode(0)
+    for b in range(B):
+        assert np.all(got[b, lens[b]:] == 0)
+    assert np.all(np.isfinite(got))
+    assert max_abs(got, base) < 1e-5 * max(1.0, float(np.abs(base).max()))
