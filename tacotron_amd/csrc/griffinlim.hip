@@ -339,8 +339,11 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gl_iter_kernel(const float* __r
 // transform's first radix-16 pass are zero (dft16_fwd_in10); of the inverse transform only outputs 0..9 are stored and
 // the compiler drops the rest of the last pass. Bins 0 / 512 / 1024 take the generic pair formulas (k = 0 pairs with
 // itself: Z[1024] = Z[0], W^0 = 1, the partner slot is a dummy entry behind the buffer), so the body has no branch.
+// (The plane exchanges read with inline-asm ds_read2_b32, which the compiler's wait-count insertion does not see: the
+// wait is written out here. Between such a read and its GL2_LAND nothing touches the registers read into.)
 #define GL2_LAND(v)                                                                                               \
     do {                                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
         _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) asm volatile("" : "+v"(v[i_]));                         \
     } while (0)
 
@@ -399,7 +402,10 @@ __device__ unsigned long long gl_dbg[64];
 #define GL_STAMP(i) do {} while (0)
 #endif
 
-constexpr int GL2_LDS = FFT_LDS + 8;    // + the dummy partner slot of bin pair (0, 1024) at fft_pad(1024) = 1088
+// complex elements of a wave's exchange buffer: the padded AoS image (FFT_LDS + the dummy partner slot of bin pair
+// (0, 1024) at fft_pad(1024) = 1088) or sixteen register planes of up to 144 dwords (below), whichever is larger
+constexpr int GL2_LDS = 1152;
+static_assert(GL2_LDS >= FFT_LDS + 8, "the padded image must fit");
 
 template <int WIN, int HOP>
 struct GL2Frame {
@@ -781,6 +787,43 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
     cplx* const l_17 = lds + 17 * lane;
     cplx* const l_b = lds + (lane >> 4) * 272 + (lane & 15);
     cplx* const l_m = lds + (192 - lane) + ((192 - lane) >> 4);
+    // ---- Register-plane exchanges (round 3). What an exchange costs is its WRITES: a ds_write moves its address and data
+    // registers to the LDS at 2 cycles per dword (6 per complex element as ds_write_b64), and dropping every other
+    // write of the four exchanges (wrong results) took 14 % off the kernel, dropping reads 2.5 %. ds_write_addtid_b32
+    // takes no address register (address = M0 + offset + 4 lane): 4 cycles per element as a pair. Its places are
+    // lane-linear, so the layout is the WRITER's: register r of lane l goes to plane r, [re: 64 lanes | im: 64 lanes],
+    // planes S dwords apart; the reader works out which (register, lane) holds the element it wants and fetches
+    // (re, im) with one ds_read2_b32 (offsets o, o + 64). S is chosen per exchange so that the reader's 32-lane groups
+    // hit 32 different banks. Used by the three exchanges whose readers stay conflict-free (pass 1 -> 2, pass 2 ->
+    // radix-4 pass, radix-4 pass -> pass 2 backwards); the last one (pass 2 -> pass 1 backwards) would read lanes 16 b
+    // apart in one plane, 2-way on 32 banks whatever S is, and keeps the padded image. Same values moved: same bits.
+    // -DGL_EXP_AOS_EXCHANGE: all four through the padded image (before).
+#ifndef GL_EXP_AOS_EXCHANGE
+    constexpr int XS1 = 130, XS2 = 144, XS3 = 132;     // plane strides (dwords): 2 / 16 / 4 (mod 32) as the readers need
+    static_assert(16 * XS2 <= 2 * GL2_LDS, "planes fit the wave's buffer");
+    const float* const pf = reinterpret_cast<const float*>(lds);
+    const unsigned lds_m0 = (unsigned)(size_t)lds;      // (the low half of a flat LDS address is the LDS byte address)
+#define GL_AT_BEGIN() asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(lds_m0) : "memory")
+#define GL_AT(val, S, r)                                                                                          \
+    asm volatile("ds_write_addtid_b32 %0 offset:%2\n\tds_write_addtid_b32 %1 offset:%3"                            \
+                 :: "v"((val).x), "v"((val).y), "n"(4 * ((r) * (S))), "n"(4 * ((r) * (S) + 64)) : "memory")
+    // (re, im) of one element with ONE ds_read2_b32 (offsets o, o + 64 dwords from a lane's byte address). As two plain
+    // loads the compiler pairs neighbouring ELEMENTS' real parts instead and rebuilds the pairs with register moves.
+#define GL_PRD(dst, addr, o)                                                                                      \
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(o), "n"((o) + 64) : "memory")
+    (void)pf;
+    const unsigned x1b = lds_m0 + 4u * (unsigned)((lane & 15) * XS1 + (lane >> 4));
+    auto x_pass1 = [&](Fr& f) {
+        // writer: lane t holds y1[16 t + c] in register c; reader l wants y1[l + 64 i] = register l & 15 of lane
+        // (l >> 4) + 4 i
+        GL_AT_BEGIN();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) GL_AT(f.v[c], XS1, c);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) GL_PRD(f.v[i], x1b, 4 * i);
+        GL_PIN();
+    };
+#else
     auto x_pass1 = [&](Fr& f) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) GL_WRI(l_17 + c, c, f.v[c]);
@@ -788,12 +831,35 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
         for (int i = 0; i < 16; ++i) f.v[i] = GL_RDI(l_r + 68 * i, i);
         GL_PIN();
     };
+#endif
     // Pass 2 writes y2[(t - k) 16 + k + 16 c]; the radix-4 pass that follows reads butterfly t's inputs y2[t + 256 i].
     // Which four butterflies a lane takes is free: here t = l, 64 + l, 192 - l, 256 - l (lane 0: 0, 64, 192, 128), so
     // that the outputs X[t + 256 i'] of a lane contain BOTH members of each of its eight bin pairs (k, 1024 - k): the
     // split / re-phase / merge of the real transform then works on registers alone, with no partner exchange through
     // LDS before and after it, and the inverse transform runs the three passes backwards from the same registers.
     cplx* const l_t = lds + t3l + (t3l >> 4);
+    (void)l_b; (void)l_m; (void)l_t; (void)l_17;
+#ifndef GL_EXP_AOS_EXCHANGE
+    // writer: lane t holds y2[256 (t >> 4) + 16 c + (t & 15)] in register c; the reader wants y2[tq + 256 i] for its
+    // butterflies tq = l, 64 + l, 192 - l, t3l: register tq >> 4 of lane 16 i + (tq & 15)
+    const unsigned x2b0 = lds_m0 + 4u * (unsigned)((lane >> 4) * XS2 + (lane & 15));
+    const unsigned x2b1 = x2b0 + 4u * 4u * XS2;
+    const unsigned x2b2 = lds_m0 + 4u * (unsigned)(((192 - lane) >> 4) * XS2 + ((192 - lane) & 15));
+    const unsigned x2b3 = lds_m0 + 4u * (unsigned)((t3l >> 4) * XS2 + (t3l & 15));
+    auto x_pass2 = [&](Fr& f) {
+        GL_AT_BEGIN();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) GL_AT(f.v[c], XS2, c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            GL_PRD(f.v[4 * i], x2b0, 16 * i);
+            GL_PRD(f.v[4 * i + 1], x2b1, 16 * i);
+            GL_PRD(f.v[4 * i + 2], x2b2, 16 * i);
+            GL_PRD(f.v[4 * i + 3], x2b3, 16 * i);
+        }
+        GL_PIN();
+    };
+#else
     auto x_pass2 = [&](Fr& f) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) GL_WRI(l_b + 17 * c, c, f.v[c]);
@@ -806,6 +872,7 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
         }
         GL_PIN();
     };
+#endif
     auto m2f = [&](Fr& f) {
         cplx (&v)[16] = f.v;
         cmul_v4(v[1], v[2], v[3], v[4], tw2[0], tw2[1], tw2[2], tw2[3]);
@@ -881,6 +948,32 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
         cmul_vc4(f.v[14], f.v[7], f.v[11], f.v[15], tw[8], tw[9], tw[10], tw[11]);
     };
     // the exchanges of the inverse are the forward ones backwards: written where the forward pass read, read where it wrote
+#ifndef GL_EXP_AOS_EXCHANGE
+    // writer: lane l holds y2'[tq_s(l) + 256 i] in register 4 i + s (tq_s = l, 64 + l, 192 - l, t3l); reader t wants
+    // y2'[256 (t >> 4) + 16 c + k], k = t & 15, i.e. butterfly tq = 16 c + k, input i = t >> 4: c < 4 -> s = 0, lane
+    // 16 c + k; c = 4..7 -> s = 1, lane 16 (c - 4) + k; tq in [129, 192] -> s = 2, lane 192 - tq; tq in [193, 255] -> s = 3,
+    // lane 256 - tq; tq = 128 (c = 8, k = 0) is lane 0's fourth butterfly, tq = 192 (c = 12, k = 0) lane 0's third
+    const int x3k = lane & 15;
+    const unsigned x3a = lds_m0 + 4u * (unsigned)(4 * (lane >> 4) * XS3 + x3k);          // plane 4 i, lane k
+    const unsigned x3b = lds_m0 + 4u * (unsigned)((4 * (lane >> 4) + 2) * XS3 - x3k);     // plane 4 i + 2, lane -k
+    auto x3 = [&](Fr& f) {
+        GL_AT_BEGIN();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) GL_AT(f.v[r], XS3, r);
+        const unsigned o8 = x3k ? x3b + 4u * 64u : x3b + 4u * XS3;      // (k = 0: plane 4 i + 3, lane 0)
+        const unsigned o12 = x3k ? x3b + 4u * (XS3 + 64u) : x3b;        // (k = 0: plane 4 i + 2, lane 0)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c < 4) GL_PRD(f.v[c], x3a, 16 * c);
+            else if (c < 8) GL_PRD(f.v[c], x3a, XS3 + 16 * (c - 4));
+            else if (c == 8) GL_PRD(f.v[c], o8, 0);
+            else if (c < 12) GL_PRD(f.v[c], x3b, 192 - 16 * c);
+            else if (c == 12) GL_PRD(f.v[c], o12, 0);
+            else GL_PRD(f.v[c], x3b, XS3 + 256 - 16 * c);
+        }
+        GL_PIN();
+    };
+#else
     auto x3 = [&](Fr& f) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -893,6 +986,7 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
         for (int c = 0; c < 16; ++c) f.v[c] = GL_RDI(l_b + 17 * c, c);
         GL_PIN();
     };
+#endif
     // pass 2 backwards: inverse 16-point DFT, then the conjugate twiddles (tw = T2 again, read once per pair)
     auto m2i = [&](Fr& f) {
         dft16<true>(f.v);
@@ -902,6 +996,20 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
         cmul_vc4(v[9], v[10], v[11], v[12], tw2[8], tw2[9], tw2[10], tw2[11]);
         cmul_vc3(v[13], v[14], v[15], tw2[12], tw2[13], tw2[14]);
     };
+#ifndef GL_EXP_AOS_EXCHANGE
+    // (the padded image; its reads as single ds_read_b64 - 2 LDS-array cycles an element where the compiler's pairs,
+    // ds_read2_b64, take 8 per two - hand-issued like the plane reads and waited for by GL2_LAND)
+    const unsigned x4b = lds_m0 + 8u * 17u * (unsigned)lane;
+    auto x4 = [&](Fr& f) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) l_r[68 * i] = f.v[i];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(f.v[c]) : "v"(x4b), "n"(8 * c) : "memory");
+        GL_PIN();
+    };
+#else
     auto x4 = [&](Fr& f) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) GL_WRI(l_r + 68 * i, i, f.v[i]);
@@ -909,6 +1017,7 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
         for (int c = 0; c < 16; ++c) f.v[c] = GL_RDI(l_17 + c, c);
         GL_PIN();
     };
+#endif
     // pass 1 backwards: v[i] = 1024 z'[lane + 64 i]; window, store (the two frames of a pair separately: sharing the
     // window read between them bunches their stores and measured slower, 7.45 against 7.34 ms)
     auto m7 = [&](Fr& f, bool store) {
@@ -1109,11 +1218,11 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
             if constexpr (SOUT) gl_lds_barrier();           // (B1) every input of the round is in registers
 #ifdef GL_EXP_SINGLE   // (experiment: the two frames one after the other, no interleave: what one frame costs a wave)
             const int fn = fi + 2 * GL_WAVES;
-            d1(A); x_pass1(A); m2f(A); dft16<false>(A.v); x_pass2(A); m3(A, mkA, mnA, m512A); x3(A);
+            d1(A); x_pass1(A); GL2_LAND(A.v); m2f(A); dft16<false>(A.v); x_pass2(A); GL2_LAND(A.v); m3(A, mkA, mnA, m512A); x3(A); GL2_LAND(A.v);
             if (fn < nfr) load_mag(mkA, mnA, m512A, fn);
             m2i(A); x4(A);
             if constexpr (SOUT) m7s(A, fi, 0, true, true); else m7(A, true);
-            d1(Bf); x_pass1(Bf); m2f(Bf); dft16<false>(Bf.v); x_pass2(Bf); m3(Bf, mkB, mnB, m512B); x3(Bf);
+            d1(Bf); x_pass1(Bf); GL2_LAND(Bf.v); m2f(Bf); dft16<false>(Bf.v); x_pass2(Bf); GL2_LAND(Bf.v); m3(Bf, mkB, mnB, m512B); x3(Bf); GL2_LAND(Bf.v);
             if (fn < nfr) load_mag(mkB, mnB, m512B, min(fn + GL_WAVES, nfr - 1));
             m2i(Bf); x4(Bf);
             if constexpr (SOUT) m7s(Bf, fi + GL_WAVES, 1, pair, false); else m7(Bf, pair);
