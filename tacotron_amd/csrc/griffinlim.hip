@@ -794,10 +794,9 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
     // lane-linear, so the layout is the WRITER's: register r of lane l goes to plane r, [re: 64 lanes | im: 64 lanes],
     // planes S dwords apart; the reader works out which (register, lane) holds the element it wants and fetches
     // (re, im) with one ds_read2_b32 (offsets o, o + 64). S is chosen per exchange so that the reader's 32-lane groups
-    // hit 32 different banks. Used by the three exchanges whose readers stay conflict-free (pass 1 -> 2, pass 2 ->
-    // radix-4 pass, radix-4 pass -> pass 2 backwards); the last one (pass 2 -> pass 1 backwards) would read lanes 16 b
-    // apart in one plane, 2-way on 32 banks whatever S is, and keeps the padded image. Same values moved: same bits.
-    // -DGL_EXP_AOS_EXCHANGE: all four through the padded image (before).
+    // hit 32 different banks (pass 1 -> 2, pass 2 -> radix-4 pass, radix-4 pass -> pass 2 backwards; the reader of the
+    // last one, pass 2 -> pass 1 backwards, takes lanes 16 b apart of one plane, 2-way whatever S is). Same values
+    // moved: same bits. -DGL_EXP_AOS_EXCHANGE: all four through the padded image (before).
 #ifndef GL_EXP_AOS_EXCHANGE
     constexpr int XS1 = 130, XS2 = 144, XS3 = 132;     // plane strides (dwords): 2 / 16 / 4 (mod 32) as the readers need
     static_assert(16 * XS2 <= 2 * GL2_LDS, "planes fit the wave's buffer");
@@ -838,7 +837,7 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
     // split / re-phase / merge of the real transform then works on registers alone, with no partner exchange through
     // LDS before and after it, and the inverse transform runs the three passes backwards from the same registers.
     cplx* const l_t = lds + t3l + (t3l >> 4);
-    (void)l_b; (void)l_m; (void)l_t; (void)l_17;
+    (void)l_b; (void)l_m; (void)l_t; (void)l_17; (void)l_r;
 #ifndef GL_EXP_AOS_EXCHANGE
     // writer: lane t holds y2[256 (t >> 4) + 16 c + (t & 15)] in register c; the reader wants y2[tq + 256 i] for its
     // butterflies tq = l, 64 + l, 192 - l, t3l: register tq >> 4 of lane 16 i + (tq & 15)
@@ -997,16 +996,16 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
         cmul_vc3(v[13], v[14], v[15], tw2[12], tw2[13], tw2[14]);
     };
 #ifndef GL_EXP_AOS_EXCHANGE
-    // (the padded image; its reads as single ds_read_b64 - 2 LDS-array cycles an element where the compiler's pairs,
-    // ds_read2_b64, take 8 per two - hand-issued like the plane reads and waited for by GL2_LAND)
-    const unsigned x4b = lds_m0 + 8u * 17u * (unsigned)lane;
+    // writer: lane l holds y1'[l + 64 i] in register i; reader t wants y1'[16 t + c] = register t >> 2 of lane
+    // 16 (t & 3) + c. (Lanes 16 b apart of one plane: 2-way on 32 banks whatever the plane stride; measured against the
+    // padded image with single ds_read_b64 reads it is still the faster form, 5.83 against 5.93 ms.)
+    const unsigned x4p = lds_m0 + 4u * (unsigned)((lane >> 2) * XS1 + 16 * (lane & 3));
     auto x4 = [&](Fr& f) {
+        GL_AT_BEGIN();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) l_r[68 * i] = f.v[i];
-        asm volatile("" ::: "memory");
+        for (int i = 0; i < 16; ++i) GL_AT(f.v[i], XS1, i);
 #pragma unroll
-        for (int c = 0; c < 16; ++c)
-            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(f.v[c]) : "v"(x4b), "n"(8 * c) : "memory");
+        for (int c = 0; c < 16; ++c) GL_PRD(f.v[c], x4p, c);
         GL_PIN();
     };
 #else
