@@ -173,3 +173,21 @@ def test_plan_batches_covers_every_utterance_once():
         assert all(first[r] < world for r in first)                # every device gets its first batch up front
         flat = np.concatenate([lens[s] for s in shards]) if n else np.zeros(0, int)
         assert np.array_equal(flat[gather_order(shards)], lens)
+
+
+def test_gl_hand_issued_lds_reads_are_waited_for(tmp_path):
+    """gl_iter2_kernel issues its exchange reads as inline asm, which the compiler's wait-count insertion does not see;
+    the wait is written into GL2_LAND. Compile the source to assembly and check that nothing touches a register between
+    its hand-issued read and that wait (tools/check_asm_reads.py)."""
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc here')
+    asm = tmp_path / 'gl.s'
+    src = os.path.join(ROOT, 'tacotron_amd', 'csrc', 'griffinlim.hip')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-S', '--cuda-device-only', '-o',
+                    str(asm), src], check=True, capture_output=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_asm_reads.py'), str(asm)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    m = re.search(r'checked[^:]*: (\d+), violations: 0', r.stdout)
+    assert m and int(m.group(1)) >= 300, r.stdout[-500:]
