@@ -736,6 +736,14 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int i = 0; i < 3; ++i) tw[3 * q + i] = T3[i * 256 + lane + 64 * q];
+    // ... and the split twiddles of the lane's eight bin pairs: read inside m3 they would be issued BEHIND the other
+    // frame's exchange, and the LDS returns a wave's reads in order - m3 could not start before that exchange had
+    // landed (stamps: m3 took 5-7 k cycles beside a transforming neighbour, 2.3 k otherwise)
+#ifndef GL_EXP_WK_LDS
+    cplx wkr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wkr[j] = wk_s[lane + 64 * j];
+#endif
     auto a1 = [&](Fr& f, Fr& g) {
         // analysis window, even/odd packing z[c] = (y[2c], y[2c+1]), c = lane + 64 i: i <= 8 always inside the window,
         // i = 9 for the first HALF - 576 lanes, i >= 10 never
@@ -802,6 +810,11 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
     static_assert(16 * XS2 <= 2 * GL2_LDS, "planes fit the wave's buffer");
     const float* const pf = reinterpret_cast<const float*>(lds);
     const unsigned lds_m0 = (unsigned)(size_t)lds;      // (the low half of a flat LDS address is the LDS byte address)
+#ifdef GL_EXP_NO_EXCHANGE   // (experiment, wrong results: the exchanges move nothing - what the kernel costs without them)
+#define GL_AT_BEGIN() do {} while (0)
+#define GL_AT(val, S, r) asm volatile("" :: "v"((val).x), "v"((val).y))
+#define GL_PRD(dst, addr, o) asm volatile("" : "+v"(dst) : "v"(addr))
+#else
 #define GL_AT_BEGIN() asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(lds_m0) : "memory")
 #define GL_AT(val, S, r)                                                                                          \
     asm volatile("ds_write_addtid_b32 %0 offset:%2\n\tds_write_addtid_b32 %1 offset:%3"                            \
@@ -810,6 +823,7 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
     // loads the compiler pairs neighbouring ELEMENTS' real parts instead and rebuilds the pairs with register moves.
 #define GL_PRD(dst, addr, o)                                                                                      \
     asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(o), "n"((o) + 64) : "memory")
+#endif
     (void)pf;
     const unsigned x1b = lds_m0 + 4u * (unsigned)((lane & 15) * XS1 + (lane >> 4));
     auto x_pass1 = [&](Fr& f) {
@@ -906,7 +920,11 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
             cplx Wk[4], E[4], Tt[4], Xk[4], Un[4];       // are one statement each
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+#ifndef GL_EXP_WK_LDS
+                Wk[j] = wkr[h + j];
+#else
                 Wk[j] = GL_RD(wk_s + lane + 64 * (h + j));
+#endif
                 const cplx zk = f.v[RK[h + j]];
                 const cplx cn = cconj(f.v[RN[h + j]]);
                 E[j] = cadd(zk, cn);
