@@ -1094,19 +1094,25 @@ __global__ __launch_bounds__(GL_THREADS, GL_EXP_LB) void gl_iter2_kernel(const f
                     const float2 val = make_float2(f.v[i].x * sc * wv.x, f.v[i].y * sc * wv.y);
                     if (o < th) rec_store2(hraw + o, val);
                     else if (o < HEAD) *reinterpret_cast<float2*>(pv + o) = val;
-                    else *reinterpret_cast<float2*>(dest(HOP * fidx + o)) = val;
+                    else *reinterpret_cast<float2*>(yseg + HOP * fidx + o) = val;     // (fidx < 3: never the side buffer)
                 }
             }
         } else {
+            // whether the frame's last HOP samples (hop fidx + 3) lie in the side buffer (hops 8..10 of the run) is the
+            // same for all of them: one scalar base instead of a test per lane and element
+            static_assert(HEAD == 3 * HOP && 2 * GL_WAVES * HOP % HOP == 0, "dest() is uniform over a frame's last hop");
+            const bool sd = (unsigned)(fidx + 3 - 2 * GL_WAVES) < (unsigned)(HEAD / HOP);
+            float* const tl = (sd ? side_s - 2 * GL_WAVES * HOP : yseg) + HOP * fidx + 2 * lane;
+            float* const pl = pv + 2 * lane;
 #pragma unroll
             for (int i = 0; i < 10; ++i) {
-                const int c = lane + 64 * i, o = 2 * c;
+                const int c = lane + 64 * i;
                 if (i < 9 || c < HALF) {
                     const float2 wv = wreg[i];
                     const float2 val = make_float2(f.v[i].x * sc * wv.x, f.v[i].y * sc * wv.y);
-                    if (128 * i + 126 < HEAD) *reinterpret_cast<float2*>(pv + o) = val;
-                    else if (128 * i >= HEAD) *reinterpret_cast<float2*>(dest(HOP * fidx + o)) = val;
-                    else *reinterpret_cast<float2*>(o < HEAD ? pv + o : dest(HOP * fidx + o)) = val;
+                    if (128 * i + 126 < HEAD) *reinterpret_cast<float2*>(pl + 128 * i) = val;
+                    else if (128 * i >= HEAD) *reinterpret_cast<float2*>(tl + 128 * i) = val;
+                    else *reinterpret_cast<float2*>((2 * c < HEAD ? pl : tl) + 128 * i) = val;
                 }
             }
         }
