@@ -201,7 +201,7 @@ def main():
                     help='0 eager per-stage kernels, 1 hipGraph, 2 persistent kernel (32 workgroups per 16 utterances: '
                          'latency), 3 tile kernel (one workgroup per 16 utterances: throughput, wants --streams >= 12)')
     ap.add_argument('--bigru-mode', type=int, default=0,
-                    help='CBHG BiGRU scan in the throughput legs: 0 = one utterance per workgroup, 1 = sixteen on MFMA')
+                    help='CBHG BiGRU scan in the throughput legs: 0 = one utterance per workgroup, 1 / 2 = sixteen / four on MFMA')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',

@@ -228,10 +228,12 @@ int taco_set_gl_split(taco_handle h, int32_t groups);
 /* Scheduling knob of the CBHG's bidirectional GRU (model/modules.py:92-98; no reference counterpart: TF picks its own
  * kernels). 0 (default): one workgroup scans one direction of ONE utterance (0.64 us per time step, 2 B workgroups of a
  * CU each: the latency path, and the only one for cell counts other than 128). 1: one workgroup scans one direction of
- * SIXTEEN utterances with the recurrent products on fp32 MFMA (~2.6 us per time step, B / 8 workgroups): a quarter of
- * the CU time per batch, for callers that keep several batches in flight. Both modes compute each utterance
- * independently of what it is batched with, in a fixed summation order of their own: results are batch-invariant
- * within a mode and differ between the modes in the last bits (both are tested against the oracle). */
+ * SIXTEEN utterances with the recurrent products on fp32 MFMA (16x16x4; 3.5 us per time step, B / 8 workgroups): a
+ * quarter of the CU time per batch. 2: FOUR utterances per workgroup on the 4x4x1 MFMA (1.9 us per step, B / 2
+ * workgroups). Every mode computes each utterance independently of what it is batched with, in a fixed summation order
+ * of its own: results are batch-invariant within a mode and differ between the modes in the last bits (all are tested
+ * against the oracle). Measured with six batches in flight (B = 32): 9.28 / 8.54 / 8.85 M frames/s for modes 0 / 1 / 2 -
+ * the longer chain of a batch costs more than the freed CUs give back, so 0 is what the repository's callers use. */
 int taco_set_bigru_mode(taco_handle h, int32_t mode);
 
 /* Synchronous check of the last persistent decode (reads a few device words; call after the stream has been

@@ -84,6 +84,7 @@ struct CbhgW {
     float* Pg = nullptr;     // [2][64][512]
     float* Pc = nullptr;     // [2][32][512]
     float* Pm = nullptr;     // [2][8][96][64]: the A-operand image of bigru_scan_mfma_kernel (128 cells only)
+    float* Pm4 = nullptr;    // [2][8][96][64]: the A-operand image of bigru_scan_mfma4_kernel (128 cells only)
 };
 
 struct GraphEntry {
@@ -362,6 +363,21 @@ struct Loader {
                         }
             cb.Pm = upload(pm);
             if (!cb.Pm) return false;
+            // ... and of the four-utterance variant: wave w owns cells 16 w .. 16 w + 15, lane l = (row group q = l / 16,
+            // cell 16 w + l % 16); register k (< 64): the gates' W[k + 64 (q / 2)][reset (q even) / update (q odd) cell];
+            // register 64 + k (k < 32): the candidate's W[32 q + k][cell]
+            std::vector<float> pm4((size_t)2 * 8 * 96 * 64);
+            for (int d = 0; d < 2; ++d)
+                for (int w = 0; w < 8; ++w)
+                    for (int i = 0; i < 96; ++i)
+                        for (int l = 0; l < 64; ++l) {
+                            const int n = 16 * w + (l & 15), qq = l >> 4;
+                            pm4[(((size_t)d * 8 + w) * 96 + i) * 64 + l] =
+                                i < 64 ? gk[d]->data[(size_t)(D + i + 64 * (qq >> 1)) * 2 * G + ((qq & 1) ? G : 0) + n]
+                                       : ck[d]->data[(size_t)(D + 32 * qq + (i - 64)) * G + n];
+                        }
+            cb.Pm4 = upload(pm4);
+            if (!cb.Pm4) return false;
         }
         return true;
     }
@@ -565,6 +581,7 @@ int run_cbhg(taco_ctx* c, const CbhgW& cb, const float* x, const int32_t* lens, 
         launch_cbhg_tail(t, s, tm);
 #ifndef TACO_EXP_NO_BIGRU   // (timing experiment, wrong results: what the chip does with the scan's work gone)
         if (c->bigru_mode == 1 && cb.Pm) launch_bigru_scan_mfma(xp, cb.Pm, lens, out, B, T, s, tm);
+        else if (c->bigru_mode == 2 && cb.Pm4) launch_bigru_scan_mfma4(xp, cb.Pm4, lens, out, B, T, s, tm);
         else launch_bigru_scan(xp, cb.Pg, cb.Pc, lens, out, B, T, cb.gru, s, tm);
 #else
         (void)hipMemsetAsync(out, 0, (size_t)M * 2 * cb.gru * sizeof(float), s);
@@ -586,6 +603,7 @@ int run_cbhg(taco_ctx* c, const CbhgW& cb, const float* x, const int32_t* lens, 
                  cb.rnn_in.bias, nullptr, nullptr, nullptr, 0, xp, 6 * cb.gru, ACT_NONE, 0};
     launch_conv_gemm(g, s, tm);
     if (c->bigru_mode == 1 && cb.Pm) launch_bigru_scan_mfma(xp, cb.Pm, lens, out, B, T, s, tm);
+    else if (c->bigru_mode == 2 && cb.Pm4) launch_bigru_scan_mfma4(xp, cb.Pm4, lens, out, B, T, s, tm);
     else launch_bigru_scan(xp, cb.Pg, cb.Pc, lens, out, B, T, cb.gru, s, tm);
     return 0;
 }
@@ -1494,7 +1512,7 @@ extern "C" int taco_set_gl_split(taco_handle h, int32_t groups) {
 
 extern "C" int taco_set_bigru_mode(taco_handle h, int32_t mode) {
     if (!h) return fail("taco_set_bigru_mode: null handle");
-    if (mode != 0 && mode != 1) return fail("taco_set_bigru_mode: mode must be 0 (latency) or 1 (throughput)");
+    if (mode < 0 || mode > 2) return fail("taco_set_bigru_mode: mode must be 0 (one utterance a workgroup), 1 (sixteen) or 2 (four)");
     h->bigru_mode = mode;
     return 0;
 }

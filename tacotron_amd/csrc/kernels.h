@@ -100,6 +100,9 @@ constexpr int BIGRU_THREADS = 512;
 // [2 directions][8 waves][96][64 lanes] is the A-operand register image (api.hip).
 void launch_bigru_scan_mfma(const float* xp, const float* Pm, const int32_t* lens, float* out, int B, int T,
                             hipStream_t s, Timing* tm);
+// ... and four utterances per workgroup on the 4x4x1 MFMA (bigru_scan_mfma4_kernel); Pm4 [2][8 waves][96][64 lanes].
+void launch_bigru_scan_mfma4(const float* xp, const float* Pm4, const int32_t* lens, float* out, int B, int T,
+                             hipStream_t s, Timing* tm);
 void launch_bigru_scan(const float* xp, const float* Pg, const float* Pc, const int32_t* lens, float* out,
                        int B, int T, int G, hipStream_t s, Timing* tm);
 

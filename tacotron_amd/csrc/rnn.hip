@@ -328,6 +328,159 @@ void launch_bigru_scan_mfma(const float* xp, const float* Pm, const int32_t* len
     if (tm) tm->end(KK_BIGRU, s);
 }
 
+// A third form (taco_set_bigru_mode 2; 128 cells): FOUR utterances per 512-thread workgroup on
+// v_mfma_f32_4x4x1_16B_f32 - sixteen independent 4x4 outer products an instruction: a block's four rows are four cells,
+// its four columns the four utterances, K = 1. One MFMA covers 64 rows (lane l supplies the A operand of row l) times 4
+// utterances for one k, in 8 cycles, so a step's 128 x 384 products per utterance cost 96 MFMAs a wave, 2 waves a SIMD
+// = 1536 MFMA cycles: the time of the one-utterance kernel's step (whose packed FMAs are what bounds it), for four
+// utterances. Wave w owns cells 16 w .. 16 w + 15 and splits K so that its 64 rows are always full: in the gates phase
+// [reset | update | reset | update] x 16 cells, the lower 32 rows over k < 64, the upper over k >= 64 (the B operand is
+// per block, so the upper blocks are fed h[64 + k]); in the candidate phase the 16 cells over four quarters of k. The
+// partial sums and the two gates meet through lane exchanges (v_permlane32_swap, v_permlane16_swap: no LDS round trip)
+// in a fixed order. A lane's C/D fragment is four consecutive cells of one utterance (a float4); stored as quad
+// (cell / 4, utterance) of a [32 quads][4 utterances] LDS image it is what the next phase reads back as the B operands
+// of four consecutive k. Same gate order, masking and reversed backward walk as the other forms.
+constexpr int BIGRU_M4_THREADS = 512;
+__global__ __launch_bounds__(BIGRU_M4_THREADS) void bigru_scan_mfma4_kernel(
+    const float* __restrict__ xp, const float* __restrict__ Pm4, const int32_t* __restrict__ lens,
+    float* __restrict__ out, int B, int T) {
+    constexpr int H = BIGRU_H;
+    static_assert(H == 128 && BIGRU_M4_THREADS == 512, "eight waves of 16 cells each");
+    __shared__ __attribute__((aligned(16))) f32x4 hq[2][32 * 4];      // state, [quad of cells][utterance]
+    __shared__ __attribute__((aligned(16))) f32x4 rhq[32 * 4];        // r * h
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y;
+    const int q = lane >> 4, cq = (lane & 15) >> 2, col = lane & 3;   // row group, cell quad, utterance
+    const int b = blockIdx.x * 4 + col;
+    const bool has_b = b < B;
+    const int bc = has_b ? b : B - 1;
+    auto clamp_len = [&](int i) { const int l = lens ? lens[i] : T; return l < 0 ? 0 : (l > T ? T : l); };
+    const int len = has_b ? clamp_len(b) : 0;
+    int maxlen = 0;
+    for (int c = 0; c < 4; ++c) {
+        const int bb = blockIdx.x * 4 + c;
+        if (bb < B) maxlen = max(maxlen, clamp_len(bb));
+    }
+    for (int c = 0; c < 4; ++c) {                                     // zero the outputs of masked steps
+        const int bb = blockIdx.x * 4 + c;
+        if (bb >= B) break;
+        const int lc = clamp_len(bb);
+        float* orow = out + ((size_t)bb * T + lc) * (2 * H) + dir * H;
+        for (int i = tid; i < (T - lc) * (H / 4); i += BIGRU_M4_THREADS)
+            *reinterpret_cast<f32x4*>(orow + (size_t)(i / (H / 4)) * 2 * H + 4 * (i % (H / 4))) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float wa[96];
+#pragma unroll
+    for (int i = 0; i < 96; ++i) wa[i] = Pm4[(((size_t)dir * 8 + wave) * 96 + i) * 64 + lane];
+    const int cell0 = 16 * wave + 4 * cq;                             // the lane's four cells
+    const int myq = (4 * wave + cq) * 4 + col;                        // ... as a quad of the LDS images
+    f32x4 h_own = {0.f, 0.f, 0.f, 0.f};
+    if (q == 0) hq[0][myq] = h_own;
+    const float* xb = xp + (size_t)bc * T * (6 * H) + dir * 3 * H + cell0;
+    float* ob = out + (size_t)bc * T * (2 * H) + dir * H + cell0;
+    auto tpos = [&](int s) { const int sc = min(s, len - 1); return len > 0 ? (dir == 0 ? sc : len - 1 - sc) : 0; };
+    // the value of lane l ^ 32 / l ^ 16: one v_permlane32_swap / v_permlane16_swap (no LDS round trip)
+    auto x32 = [&](float x) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x),
+                                                        false, false);
+        return __builtin_bit_cast(float, (q & 2) ? r[0] : r[1]);
+    };
+    auto x16 = [&](float x) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x),
+                                                        false, false);
+        return __builtin_bit_cast(float, (q & 1) ? r[0] : r[1]);
+    };
+    // the lane's input projections: its gate (reset in the even row groups, update in the odd) and the candidate
+    constexpr int U = 4;
+    f32x4 xg_c[U], xc_c[U], xg_n[U], xc_n[U];
+    auto load_chunk = [&](int s0, f32x4 (&G)[U], f32x4 (&C)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float* p = xb + (size_t)tpos(s0 + u) * (6 * H);
+            G[u] = *reinterpret_cast<const f32x4*>(p + (q & 1) * H);
+            C[u] = *reinterpret_cast<const f32x4*>(p + 2 * H);
+        }
+    };
+    load_chunk(0, xg_c, xc_c);
+    __syncthreads();
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < maxlen; s0 += U) {
+        load_chunk(s0 + U, xg_n, xc_n);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = s0 + u;
+            if (s >= maxlen) break;
+            const int cur = s & 1;
+            // ---- gates: rows [reset | update] x 16 cells over k < 64 (lanes < 32) / k >= 64 (lanes >= 32)
+            f32x4 hb[16];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) hb[g] = hq[cur][4 * (g + 16 * (q >> 1)) + col];
+            f32x4 acc[4] = {zero4, zero4, zero4, zero4};
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[4 * g + m], hb[g][m], acc[m], 0, 0, 0);
+            }
+            const f32x4 ah = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            f32x4 gate, other;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float o = x32(ah[j]);
+                const float t = (q & 2) ? o + ah[j] : ah[j] + o;       // (k < 64) + (k >= 64), in every lane
+                gate[j] = sigmoidf_(t + xg_c[u][j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) other[j] = x16(gate[j]);
+            const f32x4 r = (q & 1) ? other : gate, uu = (q & 1) ? gate : other;
+            if (q == 0) rhq[myq] = r * h_own;
+            __syncthreads();
+            // ---- candidate: rows 16 cells x four quarters of k (row group q: k in [32 q, 32 q + 32))
+            f32x4 rb[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) rb[g] = rhq[4 * (g + 8 * q) + col];
+            f32x4 a2[4] = {zero4, zero4, zero4, zero4};
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    a2[m] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[64 + 4 * g + m], rb[g][m], a2[m], 0, 0, 0);
+            }
+            const f32x4 ap = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+            f32x4 ac;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float o1 = x16(ap[j]);
+                const float s01 = (q & 1) ? o1 + ap[j] : ap[j] + o1;   // quarters (0 + 1) or (2 + 3)
+                const float o2 = x32(s01);
+                ac[j] = (q & 2) ? o2 + s01 : s01 + o2;                 // (0 + 1) + (2 + 3)
+            }
+            if (s < len) {
+                f32x4 hn;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float c = tanhf_(ac[j] + xc_c[u][j]);
+                    hn[j] = uu[j] * h_own[j] + (1.f - uu[j]) * c;
+                }
+                h_own = hn;
+                if (q == 1) *reinterpret_cast<f32x4*>(ob + (size_t)tpos(s) * (2 * H)) = hn;
+            }
+            if (q == 0) hq[cur ^ 1][myq] = h_own;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { xg_c[u] = xg_n[u]; xc_c[u] = xc_n[u]; }
+    }
+}
+
+void launch_bigru_scan_mfma4(const float* xp, const float* Pm4, const int32_t* lens, float* out, int B, int T,
+                             hipStream_t s, Timing* tm) {
+    if (tm) tm->begin(KK_BIGRU, s);
+    hipLaunchKernelGGL(bigru_scan_mfma4_kernel, dim3((B + 3) / 4, 2), dim3(BIGRU_M4_THREADS), 0, s, xp, Pm4, lens, out,
+                       B, T);
+    if (tm) tm->end(KK_BIGRU, s);
+}
+
 void launch_bigru_scan(const float* xp, const float* Pg, const float* Pc, const int32_t* lens, float* out,
                        int B, int T, int G, hipStream_t s, Timing* tm) {
     if (tm) tm->begin(KK_BIGRU, s);

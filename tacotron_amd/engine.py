@@ -130,8 +130,8 @@ class TacoEngine:
         self._check(self.lib.taco_set_gl_split(self.handle, int(groups)))
 
     def set_bigru_mode(self, mode):
-        """CBHG BiGRU scan: 0 = one utterance per workgroup (latency, default), 1 = sixteen per workgroup on fp32 MFMA
-        (a quarter of the CU time: the setting for several batches in flight). include/taco.h."""
+        """CBHG BiGRU scan: 0 = one utterance per workgroup (default, and the fastest for every job shape measured),
+        1 / 2 = sixteen / four utterances per workgroup on fp32 MFMA (less CU time, longer chain). include/taco.h."""
         self._check(self.lib.taco_set_bigru_mode(self.handle, int(mode)))
 
     def get_persist_budget(self):

@@ -541,15 +541,16 @@ def test_very_long_input(engine, hp, weights):
         assert rel_l1(_np(o[name]), ref[name]) < 1e-3, name
 
 
+@pytest.mark.parametrize('mode', [1, 2])
 @pytest.mark.parametrize('B,T_in', [(1, 5), (3, 37), (17, 40), (33, 21)])
-def test_encode_bigru_mfma_mode(engine, hp, weights, B, T_in):
-    """The throughput variant of the BiGRU scan (taco_set_bigru_mode 1: sixteen utterances per workgroup on fp32 MFMA)
-    against the oracle through the encoder, ragged lengths, batches that fill one, two and three column groups partly;
+def test_encode_bigru_mfma_mode(engine, hp, weights, B, T_in, mode):
+    """The throughput variants of the BiGRU scan (taco_set_bigru_mode 1 / 2: sixteen / four utterances per workgroup on
+    fp32 MFMA) against the oracle through the encoder, ragged lengths, batches that fill one, two and three column groups partly;
     padded steps exactly zero; an utterance's result does not depend on what it is batched with."""
     rng = np.random.default_rng(100 * B + T_in)
     ids, lens = synth_ids(rng, B, T_in)
     ref = O.encode(ids, lens, O.cast_weights(weights, np.float64), hp)
-    engine.set_bigru_mode(1)
+    engine.set_bigru_mode(mode)
     try:
         got = _np(engine.encode(ids, lens))
         alone = _np(engine.encode(ids[B - 1:B], lens[B - 1:B]))
@@ -563,12 +564,13 @@ def test_encode_bigru_mfma_mode(engine, hp, weights, B, T_in):
     assert rel_l1(got, base) < 1e-5
 
 
+@pytest.mark.parametrize('mode', [1, 2])
 @pytest.mark.parametrize('B,T', [(2, 15), (3, 100), (18, 60), (2, 1000)])
-def test_postnet_bigru_mfma_mode(engine, hp, weights, B, T):
+def test_postnet_bigru_mfma_mode(engine, hp, weights, B, T, mode):
     rng = np.random.default_rng(B + T)
     mel = (0.3 * rng.standard_normal((B, T, 80))).astype(np.float32)
     ref = O.postnet(mel.astype(np.float64), O.cast_weights(weights, np.float64), hp)
-    engine.set_bigru_mode(1)
+    engine.set_bigru_mode(mode)
     try:
         got = _np(engine.postnet(mel))
         one = _np(engine.postnet(mel[1:2]))
@@ -578,7 +580,8 @@ def test_postnet_bigru_mfma_mode(engine, hp, weights, B, T):
     assert np.array_equal(one[0], got[1])
 
 
-def test_bigru_mfma_mode_edge_lengths(engine, hp, weights):
+@pytest.mark.parametrize('mode', [1, 2])
+def test_bigru_mfma_mode_edge_lengths(engine, hp, weights, mode):
     """Throughput BiGRU scan: utterances of length 0, 1 and T among full ones in a batch that leaves a column group
     partly empty; against the one-utterance kernel (different summation order: 1e-5) and the masking rule (A.6)."""
     rng = np.random.default_rng(77)
@@ -586,7 +589,7 @@ def test_bigru_mfma_mode_edge_lengths(engine, hp, weights):
     ids, lens = synth_ids(rng, B, T_in)
     lens[1], lens[2], lens[5], lens[20] = 0, 1, T_in, 1
     base = _np(engine.encode(ids, lens))
-    engine.set_bigru_mode(1)
+    engine.set_bigru_mode(mode)
     try:
         got = _np(engine.encode(ids, lens))
     finally:

@@ -8,4 +8,4 @@ import json
 d = json.loads([l for l in open('$O/bigru_ab.json') if l.startswith('{')][-1])
 print('streams=$st bigru_mode=$m frames/s %.4g ms/step %.3f p50 batch latency %.2f' % (d['value'], d['ms_per_step'], d['p50_batch_latency_ms']))"
 done; done
-TACO_BIGRU_MODE=1 timeout -k 10 200 python tools/time_families.py 2>&1 | tail -8
+TACO_BIGRU_MODE=2 timeout -k 10 200 python tools/time_families.py 2>&1 | tail -8
